@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the batched inversion hot path on MI355X.
+
+One "step" = one pass of the hot path (one kernel launch) over one device-resident batch of synthetic
+matrices. Default workload = BASELINE.json configs[2]: batch 100 000 of 64x64 fp64, Gauss-Jordan, on SPD inputs
+generated as R + R^T + n*I (tests/generate_inverse_matrices.m:9-18 of the reference) -- the configuration the
+north_star target ("inversions/s of 64x64 fp64 ... fraction of HBM roofline") is quoted on. `--workload` selects
+the other single-GPU configs (n16 = configs[1], chol64 = the Cholesky half of configs[2]).
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run, one rank per GPU): the batch shards by matrix index with
+no data-path collective (weak scaling: every rank inverts its own `--batch` matrices); value = matrices all ranks
+inverted / max-over-ranks time. The RCCL all-gather that reassembles results is timed separately and reported as
+`allgather_ms` (it is not part of the inversion path and not in `value`).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "cuda-matrix-inversion_amd"
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+WORKLOADS = {
+    # name: (n, algo, description)
+    "gj64": (64, "gj", "batch x 64x64 fp64 Gauss-Jordan (partial pivoting), SPD inputs, BASELINE configs[2]"),
+    "chol64": (64, "chol", "batch x 64x64 fp64 Cholesky inverse, SPD inputs, BASELINE configs[2]"),
+    "gj16": (16, "gj", "batch x 16x16 fp64 Gauss-Jordan (partial pivoting), SPD inputs, BASELINE configs[1]"),
+    "gj32": (32, "gj", "batch x 32x32 fp64 Gauss-Jordan"),
+    "gj8": (8, "gj", "batch x 8x8 fp64 Gauss-Jordan"),
+    "gj128": (128, "gj", "batch x 128x128 fp64 Gauss-Jordan"),
+}
+
+
+def make_spd(n, batch, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    r = torch.rand((batch, n, n), generator=g, dtype=torch.float64, device=device)
+    a = r + r.transpose(1, 2)
+    a.diagonal(dim1=1, dim2=2).add_(float(n))
+    return a.reshape(-1).contiguous()
+
+
+def cpu_baseline(n, algo_name, target_seconds=12.0):
+    """Oracle (oracle/liboracle.so, a C port of the reference's CPU algorithms) timed on this box's host cores,
+    OpenMP schedule(dynamic,8) over the batch as src/inverse.c:79 of the reference. Bounded sample."""
+    import oracle
+    cores = len(os.sched_getaffinity(0))
+    algo = oracle.ALGO_GJ_PIVOT if algo_name == "gj" else oracle.ALGO_CHOLESKY
+    rng = np.random.default_rng(0)
+
+    def sample(k):
+        r = rng.random((k, n, n))
+        return (r + r.transpose(0, 2, 1) + n * np.eye(n)).reshape(-1)
+
+    probe = sample(max(cores * 16, 256))
+    oracle.inverse_batched(probe, n, algo, threads=cores)  # warm-up (thread pool, page faults)
+    t0 = time.perf_counter()
+    oracle.inverse_batched(probe, n, algo, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    rate = (probe.size // (n * n)) / dt
+    k = int(min(max(rate * target_seconds, 1024), 2_000_000, 2e9 / (n * n * 8)))
+    a = sample(k)
+    t0 = time.perf_counter()
+    oracle.inverse_batched(a, n, algo, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": k / dt, "unit": "inversions/s", "cores": cores, "kind": "port",
+            "sample": f"{k} SPD {n}x{n} fp64 matrices, oracle {'Gauss-Jordan partial pivot' if algo_name == 'gj' else 'Cholesky'}"
+                      f" (C, OpenMP {cores} threads), {dt:.1f} s"}
+
+
+def load_traffic(kernel_name, n):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        table = json.load(open(p))
+    except Exception:
+        return None
+    return table.get(f"{kernel_name}|n={n}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="gj64", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=100_000, help="matrices per GPU per step")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "lds", "rowlane", "tile"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    api = importlib.import_module(PKG + ".api")
+    n, algo_name, desc = WORKLOADS[args.workload]
+    algo = api.ALGO_GAUSS_JORDAN if algo_name == "gj" else api.ALGO_CHOLESKY
+    kernel = {"auto": api.KERNEL_AUTO, "lds": api.KERNEL_LDS, "rowlane": api.KERNEL_ROWLANE,
+              "tile": api.KERNEL_TILE}[args.kernel]
+    batch = args.batch
+
+    a = make_spd(n, batch, 0x5EED + rank, device)
+    x = torch.empty_like(a)
+    info = torch.empty(batch, dtype=torch.int32, device=device)
+
+    def step():
+        api.inverse_batched(a, n, algo, out=x, info=info, kernel=kernel, batch=batch)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    assert int(info.abs().sum()) == 0, "synthetic SPD batch reported singular matrices"
+
+    # HIP events on the stream the kernel is launched on (api passes torch's current stream to the C ABI)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s, e in ev:
+        s.record()
+        step()
+        e.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+
+    gather_ms = None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        shard = importlib.import_module(PKG + ".shard")
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        full = shard.all_gather_shards(x, n, batch * world)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        assert full.numel() == batch * world * n * n
+        del full
+
+    # quick correctness guard on the timed output (not timed): residual of a few matrices
+    am = a.view(batch, n, n)[:8]
+    xm = x.view(batch, n, n)[:8]
+    resid = float((torch.bmm(am, xm) - torch.eye(n, dtype=a.dtype, device=device)).abs().max())
+    assert resid < 1e-11 * n, f"residual {resid}"
+
+    if rank == 0:
+        total = batch * world * args.steps
+        value = total / elapsed
+        bytes_per_inv = 2 * n * n * 8  # read A once + write A^-1 once
+        achieved = batch * bytes_per_inv / (kern_ms * 1e-3) / 1e9
+        kname = api.kernel_name(algo, api.F64, n, kernel)
+        out = {
+            "metric": "matrix inversions/s", "value": value, "unit": "inversions/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc.replace('batch', str(batch))}", "n": n,
+                       "batch_per_gpu": batch, "algorithm": algo_name, "kernel": kname,
+                       "sharding": f"batch block-partitioned over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kname, n),
+                         "kernel": kname, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": batch * bytes_per_inv},
+        }
+        if gather_ms is not None:
+            out["allgather_ms"] = gather_ms
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n, algo_name)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

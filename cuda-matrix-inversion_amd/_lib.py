@@ -1,0 +1,92 @@
+"""ctypes binding of libmatinv_hip.so (the C ABI declared in include/matinv.h and include/inverse_gpu.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing a compute entry point
+raises. The library is built in-tree by ``make -C cuda-matrix-inversion_amd`` (``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmatinv_hip.so")
+
+# include/matinv.h enums
+OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4
+F64, F32 = 0, 1
+ALGO_GAUSS_JORDAN, ALGO_CHOLESKY = 0, 1
+KERNEL_AUTO, KERNEL_LDS, KERNEL_ROWLANE, KERNEL_TILE = 0, 1, 2, 3
+
+REFERENCE_GPU_NAMES = [
+    "inverse_gauss_batched_gpu", "inverse_lu_cuda_batched_gpu", "inverse_cholesky_stride_batched_gpu",
+    "inverse_cholesky_batched_gpu", "inverse_cholesky_mm_batched_gpu", "inverse_cholesky_mm2_batched_gpu",
+]
+REFERENCE_DEVICE_NAMES = [
+    "inverse_gauss_batched_device", "inverse_lu_cuda_batched_device", "inverse_cholesky_stride_batched_device",
+    "decompose_cholesky_stride_batched_device", "inverse_upper_stride_batched_device",
+    "multiply_upper_stride_batched_device", "inverse_cholesky_batched_device", "decompose_cholesky_batched_device",
+    "inverse_cholesky_mm_batched_device", "decompose_cholesky_mm_batched_device",
+    "inverse_cholesky_mm2_batched_device",
+]
+NATIVE_NAMES = [
+    "matinv_inverse_batched", "matinv_inverse_batched_ex", "matinv_select_kernel", "matinv_kernel_name",
+    "matinv_mean_batched", "matinv_variance_batched", "matinv_inverse_batched_host", "matinv_last_error",
+    "matinv_abi_version",
+]
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of the shared library (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", _HERE, "-s", "clean"], check=True)
+    subprocess.run(["make", "-C", _HERE, "-s", "-j4"], check=True)
+    return LIB_PATH
+
+
+class MatinvError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libmatinv_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run __graft_entry__.build() "
+            f"(make -C cuda-matrix-inversion_amd). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.matinv_inverse_batched.restype = ci
+    L.matinv_inverse_batched.argtypes = [ci, ci, ci, vp, sz, vp, sz, sz, vp, vp]
+    L.matinv_inverse_batched_ex.restype = ci
+    L.matinv_inverse_batched_ex.argtypes = [ci, ci, ci, vp, sz, vp, sz, sz, vp, vp, ci]
+    L.matinv_select_kernel.restype = ci
+    L.matinv_select_kernel.argtypes = [ci, ci, ci]
+    L.matinv_kernel_name.restype = ctypes.c_char_p
+    L.matinv_kernel_name.argtypes = [ci, ci, ci, ci]
+    for f in (L.matinv_mean_batched, L.matinv_variance_batched):
+        f.restype = ci
+        f.argtypes = [ci, ci, vp, vp, vp, vp, vp, sz, vp, vp]
+    L.matinv_inverse_batched_host.restype = ci
+    L.matinv_inverse_batched_host.argtypes = [ci, ci, ci, vp, vp, sz, vp]
+    L.matinv_last_error.restype = ctypes.c_char_p
+    L.matinv_abi_version.restype = ci
+    for suffix in ("", "_f32"):
+        for name in REFERENCE_GPU_NAMES + REFERENCE_DEVICE_NAMES:
+            f = getattr(L, name + suffix)
+            f.restype = None
+            f.argtypes = [vp, ci, vp, vp, ci]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise MatinvError(rc, lib().matinv_last_error().decode())

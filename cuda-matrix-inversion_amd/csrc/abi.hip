@@ -1,0 +1,380 @@
+// abi.hip -- the C ABI of libmatinv_hip.so: include/matinv.h (native, device-resident, stream-aware)
+// and the 17 reference-named entry points of include/inverse_gpu.h in fp64 and (suffix _f32) fp32.
+//
+// No CPU fallback lives here: every entry point ends in a HIP kernel launch or fails loudly.
+#include <errno.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <vector>
+
+#include "../../include/matinv.h"
+#include "common.hpp"
+
+using namespace matinv;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what)
+{
+    return fail(MATINV_ERR_HIP, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+
+// The library is built for gfx950 only; refuse anything else instead of faulting in the launch.
+int check_device()
+{
+    static thread_local int checked_dev = -1;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(MATINV_ERR_NO_DEVICE, "hipGetDevice: %s", hipGetErrorString(e));
+    if (dev == checked_dev) return MATINV_OK;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MATINV_ERR_NO_DEVICE, "device %d is %s; libmatinv_hip is built for gfx950 (MI355X) only", dev,
+                    prop.gcnArchName);
+    checked_dev = dev;
+    return MATINV_OK;
+}
+
+template <class T>
+int select_auto(int algo, int n)
+{
+    if (algo == MATINV_ALGO_GAUSS_JORDAN) {
+        if (rowlane_family_supports<T>(n)) return MATINV_KERNEL_ROWLANE;
+        if (tile_family_supports<T>(n)) return MATINV_KERNEL_TILE;
+    }
+    if (lds_family_supports<T>(n)) return MATINV_KERNEL_LDS;
+    return MATINV_ERR_UNSUPPORTED;
+}
+
+template <class T>
+int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *dInfo, hipStream_t stream,
+                     int kernel, int chol_phases = 7)
+{
+    if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
+    if (algo != MATINV_ALGO_GAUSS_JORDAN && algo != MATINV_ALGO_CHOLESKY)
+        return fail(MATINV_ERR_ARG, "unknown algorithm %d", algo);
+    if (batch == 0) return MATINV_OK;
+    if (batch > 0x7fffffffu) return fail(MATINV_ERR_ARG, "batch %zu exceeds the grid limit; split the call", batch);
+    int rc = check_device();
+    if (rc) return rc;
+    if (kernel == MATINV_KERNEL_AUTO) {
+        kernel = select_auto<T>(algo, n);
+        if (kernel < 0)
+            return fail(MATINV_ERR_UNSUPPORTED, "n=%d exceeds every kernel family built in (LDS family limit)", n);
+    }
+    hipError_t e = hipErrorInvalidValue;
+    switch (kernel) {
+    case MATINV_KERNEL_LDS:
+        if (!lds_family_supports<T>(n)) return fail(MATINV_ERR_UNSUPPORTED, "LDS family: n=%d does not fit 160 KiB", n);
+        e = (algo == MATINV_ALGO_GAUSS_JORDAN) ? launch_gj_lds<T>(n, A, X, batch, dInfo, stream)
+                                               : launch_chol_lds<T>(n, A, X, batch, dInfo, stream, chol_phases);
+        break;
+    case MATINV_KERNEL_ROWLANE:
+        if (algo != MATINV_ALGO_GAUSS_JORDAN || !rowlane_family_supports<T>(n))
+            return fail(MATINV_ERR_UNSUPPORTED, "rowlane family serves Gauss-Jordan with n <= 16 only (n=%d)", n);
+        e = launch_gj_rowlane<T>(n, A, X, batch, dInfo, stream);
+        break;
+    case MATINV_KERNEL_TILE:
+        if (algo != MATINV_ALGO_GAUSS_JORDAN || !tile_family_supports<T>(n))
+            return fail(MATINV_ERR_UNSUPPORTED, "tile family serves f64 Gauss-Jordan with 16 < n <= 64 only (n=%d)", n);
+        e = launch_gj_tile<T>(n, A, X, batch, dInfo, stream);
+        break;
+    default:
+        return fail(MATINV_ERR_ARG, "unknown kernel family %d", kernel);
+    }
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return MATINV_OK;
+}
+
+template <class T>
+int inverse_strided(int algo, int n, const void *dA, size_t strideA, void *dAinv, size_t strideInv, size_t batch,
+                    int *dInfo, void *stream, int kernel)
+{
+    if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
+    if (batch && (!dA || !dAinv)) return fail(MATINV_ERR_ARG, "null device pointer");
+    if (batch > 1 && (strideA < (size_t)n * n || strideInv < (size_t)n * n))
+        return fail(MATINV_ERR_ARG, "stride smaller than n*n");
+    BatchRef<const T> A{static_cast<const T *>(dA), strideA, nullptr};
+    BatchRef<T> X{static_cast<T *>(dAinv), strideInv, nullptr};
+    return inverse_dispatch<T>(algo, n, A, X, batch, dInfo, static_cast<hipStream_t>(stream), kernel);
+}
+
+double now_ms()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+// MATINV_DETAILED_LOGGING=1 reproduces the reference's log=1 build (Makefile:115-117 there): one
+// `name,batch,n,ms,ns\r\n` line per phase (include/timer.h:8-9), same key names as the reference's
+// TIMER_LOG calls (e.g. src/gauss/batched_invert.cu:114-118,169-171).
+bool detailed_logging()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *s = getenv("MATINV_DETAILED_LOGGING");
+        v = (s && *s && *s != '0') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+void timer_log(const char *prefix, const char *phase, size_t batch, int n, double ms)
+{
+    printf("%s_%s,%zu,%d,%.4f,%lu\r\n", prefix, phase, batch, n, ms, (unsigned long)(ms * 1e6));
+}
+
+template <class T>
+int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int *info, const char *log_prefix,
+                 int kernel = MATINV_KERNEL_AUTO)
+{
+    if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
+    if (batch == 0) return MATINV_OK;
+    if (!hA || !hAinv) return fail(MATINV_ERR_ARG, "null host pointer");
+    int rc = check_device();
+    if (rc) return rc;
+    const size_t elems = (size_t)n * n * batch;  // size_t: 1M x 64 x 64 overflows the reference's int index
+    T *dA = nullptr, *dX = nullptr;
+    int *dInfo = nullptr;
+    hipError_t e;
+    const bool log = detailed_logging() && log_prefix;
+    if ((e = hipMalloc(&dA, elems * sizeof(T))) != hipSuccess) return fail_hip(e, "hipMalloc(As)");
+    if ((e = hipMalloc(&dX, elems * sizeof(T))) != hipSuccess) {
+        (void)hipFree(dA);
+        return fail_hip(e, "hipMalloc(aInvs)");
+    }
+    if (info && (e = hipMalloc(&dInfo, batch * sizeof(int))) != hipSuccess) {
+        (void)hipFree(dA);
+        (void)hipFree(dX);
+        return fail_hip(e, "hipMalloc(info)");
+    }
+    double t0 = now_ms();
+    e = hipMemcpy(dA, hA, elems * sizeof(T), hipMemcpyHostToDevice);
+    double t1 = now_ms();
+    if (e == hipSuccess) {
+        rc = inverse_strided<T>(algo, n, dA, (size_t)n * n, dX, (size_t)n * n, batch, dInfo, nullptr, kernel);
+        if (rc == MATINV_OK && log) e = hipDeviceSynchronize();
+    }
+    double t2 = now_ms();
+    if (e == hipSuccess && rc == MATINV_OK) e = hipMemcpy(hAinv, dX, elems * sizeof(T), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rc == MATINV_OK && info)
+        e = hipMemcpy(info, dInfo, batch * sizeof(int), hipMemcpyDeviceToHost);
+    double t3 = now_ms();
+    (void)hipFree(dA);
+    (void)hipFree(dX);
+    if (dInfo) (void)hipFree(dInfo);
+    if (rc != MATINV_OK) return rc;
+    if (e != hipSuccess) return fail_hip(e, "host<->device copy");
+    if (log) {
+        timer_log(log_prefix, "mem_htod", batch, n, t1 - t0);
+        timer_log(log_prefix, "ker", batch, n, t2 - t1);
+        timer_log(log_prefix, "mem_dtoh", batch, n, t3 - t2);
+    }
+    return MATINV_OK;
+}
+
+// Reference *_batched_device form: HOST-resident tables of DEVICE pointers (filled by batchedCudaMalloc,
+// /root/reference/src/helper.cu:103-118, so normally equally spaced by the pitch). Equally spaced tables are
+// passed as base + stride; anything else is staged into a device-side table that lives until the launch retires.
+template <class T>
+int inverse_table(int algo, int n, T *const *hostIn, T *const *hostOut, size_t batch, int chol_phases = 7)
+{
+    if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
+    if (batch == 0) return MATINV_OK;
+    if (!hostIn || !hostOut) return fail(MATINV_ERR_ARG, "null pointer table");
+    auto uniform = [&](T *const *tab, size_t &stride) {
+        stride = (size_t)n * n;
+        if (batch == 1) return true;
+        if (tab[1] <= tab[0]) return false;
+        stride = (size_t)(tab[1] - tab[0]);
+        if (stride < (size_t)n * n) return false;
+        for (size_t i = 2; i < batch; ++i)
+            if (tab[i] != tab[0] + i * stride) return false;
+        return true;
+    };
+    size_t sIn = 0, sOut = 0;
+    const bool uIn = uniform(hostIn, sIn), uOut = uniform(hostOut, sOut);
+    T **dTabIn = nullptr, **dTabOut = nullptr;
+    hipError_t e = hipSuccess;
+    if (!uIn) {
+        if ((e = hipMalloc(&dTabIn, batch * sizeof(T *))) != hipSuccess) return fail_hip(e, "hipMalloc(table)");
+        e = hipMemcpy(dTabIn, hostIn, batch * sizeof(T *), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !uOut) {
+        if ((e = hipMalloc(&dTabOut, batch * sizeof(T *))) == hipSuccess)
+            e = hipMemcpy(dTabOut, hostOut, batch * sizeof(T *), hipMemcpyHostToDevice);
+    }
+    int rc = MATINV_OK;
+    if (e != hipSuccess) rc = fail_hip(e, "pointer table staging");
+    if (rc == MATINV_OK) {
+        BatchRef<const T> A{hostIn[0], sIn, uIn ? nullptr : const_cast<const T *const *>(dTabIn)};
+        BatchRef<T> X{hostOut[0], sOut, uOut ? nullptr : dTabOut};
+        rc = inverse_dispatch<T>(algo, n, A, X, batch, nullptr, nullptr, MATINV_KERNEL_AUTO, chol_phases);
+    }
+    if (dTabIn || dTabOut) {
+        // rare path: the table must outlive the asynchronous launch
+        (void)hipDeviceSynchronize();
+        if (dTabIn) (void)hipFree(dTabIn);
+        if (dTabOut) (void)hipFree(dTabOut);
+    }
+    return rc;
+}
+
+template <class T>
+int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *d, const void *e_, void *out,
+                size_t batch, int *dInfo, void *stream, bool variance)
+{
+    if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
+    if (batch == 0) return MATINV_OK;
+    if (!a || !B || !c || !out || (variance ? !e_ : !d)) return fail(MATINV_ERR_ARG, "null device pointer");
+    if (batch > 0x7fffffffu) return fail(MATINV_ERR_ARG, "batch %zu exceeds the grid limit; split the call", batch);
+    int rc = check_device();
+    if (rc) return rc;
+    if (!lds_family_supports<T>(n)) return fail(MATINV_ERR_UNSUPPORTED, "pipeline: n=%d does not fit 160 KiB of LDS", n);
+    hipError_t e = launch_gp_lds<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
+                                    variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
+                                    static_cast<T *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return MATINV_OK;
+}
+
+// Reference error contract: message on stderr, then exit (include/helper_gpu.h:9-18, helper_cpu.h:12-21 there).
+void die_on(int rc, const char *fn)
+{
+    if (rc == MATINV_OK) return;
+    fprintf(stderr, "ENSURE FAILED %s\r\n%s\r\n", fn, g_err);
+    if (errno) perror("possible reason for failure from ERRNO");
+    (void)hipDeviceReset();
+    exit(EXIT_FAILURE);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int matinv_abi_version(void) { return 1; }
+const char *matinv_last_error(void) { return g_err; }
+
+int matinv_inverse_batched_ex(int algo, int dtype, int n, const void *dA, size_t strideA, void *dAinv,
+                              size_t strideInv, size_t batch, int *dInfo, void *stream, int kernel)
+{
+    if (dtype == MATINV_F64)
+        return inverse_strided<double>(algo, n, dA, strideA, dAinv, strideInv, batch, dInfo, stream, kernel);
+    if (dtype == MATINV_F32)
+        return inverse_strided<float>(algo, n, dA, strideA, dAinv, strideInv, batch, dInfo, stream, kernel);
+    return fail(MATINV_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int matinv_inverse_batched(int algo, int dtype, int n, const void *dA, size_t strideA, void *dAinv, size_t strideInv,
+                           size_t batch, int *dInfo, void *stream)
+{
+    return matinv_inverse_batched_ex(algo, dtype, n, dA, strideA, dAinv, strideInv, batch, dInfo, stream,
+                                     MATINV_KERNEL_AUTO);
+}
+
+int matinv_select_kernel(int algo, int dtype, int n)
+{
+    if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
+    int k = (dtype == MATINV_F64) ? select_auto<double>(algo, n) : select_auto<float>(algo, n);
+    if (k < 0) return fail(MATINV_ERR_UNSUPPORTED, "n=%d exceeds every kernel family built in", n);
+    return k;
+}
+
+const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
+{
+    const bool f64 = dtype == MATINV_F64;
+    if (kernel == MATINV_KERNEL_AUTO) kernel = matinv_select_kernel(algo, dtype, n);
+    switch (kernel) {
+    case MATINV_KERNEL_LDS: return algo == MATINV_ALGO_CHOLESKY ? name_chol_lds(f64) : name_gj_lds(f64);
+    case MATINV_KERNEL_ROWLANE: return name_gj_rowlane(f64, n);
+    case MATINV_KERNEL_TILE: return name_gj_tile(f64, n);
+    default: return "";
+    }
+}
+
+int matinv_mean_batched(int dtype, int n, const void *dAs, const void *dBs, const void *dCs, const void *dDs,
+                        void *dMeans, size_t batch, int *dInfo, void *stream)
+{
+    if (dtype == MATINV_F64) return gp_dispatch<double>(n, dAs, dBs, dCs, dDs, nullptr, dMeans, batch, dInfo, stream, false);
+    if (dtype == MATINV_F32) return gp_dispatch<float>(n, dAs, dBs, dCs, dDs, nullptr, dMeans, batch, dInfo, stream, false);
+    return fail(MATINV_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int matinv_variance_batched(int dtype, int n, const void *dAs, const void *dBs, const void *dCs, const void *dEs,
+                            void *dVars, size_t batch, int *dInfo, void *stream)
+{
+    if (dtype == MATINV_F64) return gp_dispatch<double>(n, dAs, dBs, dCs, nullptr, dEs, dVars, batch, dInfo, stream, true);
+    if (dtype == MATINV_F32) return gp_dispatch<float>(n, dAs, dBs, dCs, nullptr, dEs, dVars, batch, dInfo, stream, true);
+    return fail(MATINV_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int matinv_inverse_batched_host(int algo, int dtype, int n, const void *hA, void *hAinv, size_t batch, int *info)
+{
+    if (dtype == MATINV_F64) return inverse_host<double>(algo, n, hA, hAinv, batch, info, nullptr);
+    if (dtype == MATINV_F32) return inverse_host<float>(algo, n, hA, hAinv, batch, info, nullptr);
+    return fail(MATINV_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 17 reference names (include/inverse_gpu.h), fp64 under the plain name and fp32 under <name>_f32.
+// `handle` is ignored exactly as the reference's hand-written kernels ignore it.
+#define GJ MATINV_ALGO_GAUSS_JORDAN
+#define CH MATINV_ALGO_CHOLESKY
+#define REF_GPU(name, suffix, T, algo, logkey)                                                                       \
+    void name##suffix(void *handle, int n, T *As, T *aInvs, int batchSize)                                          \
+    {                                                                                                                \
+        (void)handle;                                                                                                \
+        die_on(batchSize < 0 ? fail(MATINV_ERR_ARG, "negative batchSize") : inverse_host<T>(algo, n, As, aInvs,      \
+               (size_t)batchSize, nullptr, logkey), #name);                                                          \
+    }
+#define REF_DEV(name, suffix, T, algo, in, out, phases)                                                              \
+    void name##suffix(void *handle, int N, T **devAs, T **devAInvs, int batchSize)                                  \
+    {                                                                                                                \
+        (void)handle; (void)devAs; (void)devAInvs;                                                                   \
+        die_on(batchSize < 0 ? fail(MATINV_ERR_ARG, "negative batchSize") : inverse_table<T>(algo, N, in, out,       \
+               (size_t)batchSize, phases), #name);                                                                   \
+    }
+// log keys are the reference's TIMER_INIT names for each entry point
+#define REF_ALL(suffix, T)                                                                                           \
+    REF_GPU(inverse_gauss_batched_gpu, suffix, T, GJ, "inverse_gauss_batched_gpu")             /* batched_invert.cu:99 */ \
+    REF_GPU(inverse_lu_cuda_batched_gpu, suffix, T, GJ, "inverse_lu_cuda_batched_gpu")         /* gauss/inverse_gpu.cu:60 */ \
+    REF_GPU(inverse_cholesky_batched_gpu, suffix, T, CH, "decompose_cholesky_batched_gpu")     /* inverse_cholesky_gpu.cu:397 */ \
+    REF_GPU(inverse_cholesky_mm_batched_gpu, suffix, T, CH, "decompose_cholesky_mm_batched_gpu") /* :627 */          \
+    REF_GPU(inverse_cholesky_mm2_batched_gpu, suffix, T, CH, "cholesky_mm2_batched_gpu")       /* :699 */            \
+    REF_GPU(inverse_cholesky_stride_batched_gpu, suffix, T, CH, "inverse_cholesky_stride_batched_gpu") /* :189 */    \
+    REF_DEV(inverse_gauss_batched_device, suffix, T, GJ, devAs, devAInvs, 7)   /* declared inverse_gpu.h:10, never defined there */ \
+    REF_DEV(inverse_lu_cuda_batched_device, suffix, T, GJ, devAs, devAInvs, 7) /* gauss/inverse_gpu.cu:16; input kept intact here */ \
+    REF_DEV(inverse_cholesky_batched_device, suffix, T, CH, devAs, devAInvs, 7)        /* :323 */                    \
+    REF_DEV(inverse_cholesky_mm_batched_device, suffix, T, CH, devAs, devAInvs, 7)     /* :608 */                    \
+    REF_DEV(inverse_cholesky_mm2_batched_device, suffix, T, CH, devAs, devAInvs, 7)    /* :693 */                    \
+    /* stride family works in place on devAInvs (the *_gpu wrapper copies As there first, :213-216) */              \
+    REF_DEV(inverse_cholesky_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 7)     /* :182 */             \
+    REF_DEV(decompose_cholesky_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 1)   /* :96  */             \
+    REF_DEV(inverse_upper_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 2)        /* :137 */             \
+    REF_DEV(multiply_upper_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 4)       /* :175 */             \
+    /* decompose: factor in place in devAs, strict upper triangle zeroed (:357-369, :616-624) */                    \
+    REF_DEV(decompose_cholesky_batched_device, suffix, T, CH, devAs, devAs, 1)                                       \
+    REF_DEV(decompose_cholesky_mm_batched_device, suffix, T, CH, devAs, devAs, 1)
+
+REF_ALL(, double)
+REF_ALL(_f32, float)
+
+}  // extern "C"

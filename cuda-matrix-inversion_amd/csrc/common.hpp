@@ -1,0 +1,57 @@
+// common.hpp -- shared declarations of the HIP translation units of libmatinv_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace matinv {
+
+// Where matrix k of a batch lives: either base + k*stride, or table[k] (the reference's
+// "array of device pointers" form, /root/reference/src/helper.cu:103-118).
+template <class T>
+struct BatchRef {
+    T *base;
+    size_t stride;
+    T *const *table;  // device-resident pointer table, or nullptr
+    __device__ __forceinline__ T *at(size_t k) const { return table ? table[k] : base + k * stride; }
+};
+
+template <class T>
+__device__ __forceinline__ T nan_of();
+template <>
+__device__ __forceinline__ double nan_of<double>() { return __longlong_as_double(0x7ff8000000000000LL); }
+template <>
+__device__ __forceinline__ float nan_of<float>() { return __int_as_float(0x7fc00000); }
+
+// Host-side launchers; each returns hipSuccess / an error, or hipErrorInvalidValue when the
+// family cannot serve (n, dtype). All are asynchronous on `stream`.
+template <class T>
+hipError_t launch_gj_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+// phases: bit 0 factor, bit 1 triangular inverse, bit 2 L^-T L^-1 (7 = full inverse)
+template <class T>
+hipError_t launch_chol_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
+                           int phases);
+// Ds == nullptr selects the variance form (needs Es); otherwise the mean form.
+template <class T>
+hipError_t launch_gp_lds(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                         int *info, hipStream_t stream);
+template <class T>
+bool lds_family_supports(int n);
+
+template <class T>
+hipError_t launch_gj_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+bool rowlane_family_supports(int n);
+
+template <class T>
+hipError_t launch_gj_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+bool tile_family_supports(int n);
+
+const char *name_gj_rowlane(bool f64, int n);
+const char *name_gj_tile(bool f64, int n);
+const char *name_gj_lds(bool f64);
+const char *name_chol_lds(bool f64);
+const char *name_gp_lds(bool f64);
+
+}  // namespace matinv

@@ -1,0 +1,100 @@
+/*
+ * matinv.h -- native C ABI of the MI355X batched small-matrix inversion engine
+ * (libmatinv_hip.so). Plain pointers and sizes only; no C++/torch types.
+ *
+ * This is the device-resident, stream-aware core that the reference-named
+ * entry points of inverse_gpu.h are thin wrappers over. A matrix is n x n,
+ * column-major (element (r,c) at c*n + r), and matrix k of a batch starts at
+ * base + k*stride elements (stride >= n*n; the reference uses a pitched
+ * allocation, /root/reference/src/helper.cu:103-118, so a stride is needed to
+ * accept its device tables without a copy).
+ *
+ * All functions return MATINV_OK (0) or a negative matinv_status and never
+ * call exit(); matinv_last_error() describes the last failure of the calling
+ * thread. The reference-named wrappers keep the reference's fatal behaviour
+ * (include/helper_gpu.h:9-18 there) on top of this.
+ */
+#ifndef MATINV_H_INCLUDED
+#define MATINV_H_INCLUDED
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MATINV_OK = 0,
+    MATINV_ERR_ARG = -1,         /* bad n / batch / pointer / stride                   */
+    MATINV_ERR_UNSUPPORTED = -2, /* n too large for every kernel family built in       */
+    MATINV_ERR_HIP = -3,         /* a HIP runtime call failed (message in last_error)  */
+    MATINV_ERR_NO_DEVICE = -4    /* no gfx950 device visible                           */
+} matinv_status;
+
+typedef enum {
+    MATINV_F64 = 0,
+    MATINV_F32 = 1
+} matinv_dtype;
+
+typedef enum {
+    MATINV_ALGO_GAUSS_JORDAN = 0, /* general matrices, partial pivoting. Replaces pivotRow/normalizeRow/
+                                     transform_matrix, src/gauss/batched_invert.cu:17-95, and the cuBLAS LU
+                                     path src/gauss/inverse_gpu.cu:16-58                                   */
+    MATINV_ALGO_CHOLESKY = 1      /* SPD matrices (only the lower triangle is read), full symmetric result.
+                                     Replaces the four Cholesky families of src/inverse_cholesky_gpu.cu     */
+} matinv_algo;
+
+/* Kernel families; MATINV_KERNEL_AUTO picks by (algo, dtype, n). The others force one family and
+ * fail with MATINV_ERR_UNSUPPORTED when it cannot handle the request (used by tests and bench). */
+typedef enum {
+    MATINV_KERNEL_AUTO = 0,
+    MATINV_KERNEL_LDS = 1,     /* one workgroup per matrix, matrix resident in LDS, any n up to the LDS limit */
+    MATINV_KERNEL_ROWLANE = 2, /* n <= 16: 64/npad matrices per wavefront, one row per lane, DPP broadcasts     */
+    MATINV_KERNEL_TILE = 3     /* 16 < n <= 64 (f64): one matrix per wavefront in 16x16 MFMA tiles             */
+} matinv_kernel;
+
+/* Invert `batch` matrices that are already resident in device memory.
+ *   dA      in : batch matrices, matrix k at dA + k*strideA (elements). Never written.
+ *   dAinv   out: matrix k at dAinv + k*strideInv. May be exactly dA with strideInv == strideA (in place:
+ *                every kernel reads a whole matrix before writing it); partial overlap is undefined.
+ *   dInfo   out: optional int[batch] (device). 0 = ok; k+1 = no usable pivot at elimination step k
+ *                (Gauss-Jordan: singular) or leading minor k+1 not positive (Cholesky: not SPD).
+ *                The output matrix is unspecified for info != 0.
+ *   stream     : hipStream_t as void* (NULL = default stream). Asynchronous.
+ */
+int matinv_inverse_batched(int algo, int dtype, int n, const void *dA, size_t strideA, void *dAinv,
+                           size_t strideInv, size_t batch, int *dInfo, void *stream);
+
+/* Same, forcing a kernel family (matinv_kernel). */
+int matinv_inverse_batched_ex(int algo, int dtype, int n, const void *dA, size_t strideA, void *dAinv,
+                              size_t strideInv, size_t batch, int *dInfo, void *stream, int kernel);
+
+/* Which family MATINV_KERNEL_AUTO resolves to (a matinv_kernel), or a negative status. */
+int matinv_select_kernel(int algo, int dtype, int n);
+
+/* Name of the __global__ function a (algo, dtype, n, kernel) request launches -- the name rocprofv3 reports. */
+const char *matinv_kernel_name(int algo, int dtype, int n, int kernel);
+
+/* Fused Gaussian-process pipeline, device-resident (replaces calcluateMean / calcluateVariance,
+ * src/gauss_bench.cu:127-265,275-409: addDiagonal + batched inverse + two gemmBatched):
+ *   means[k] = a_k^T (B_k + diag(c_k))^-1 d_k
+ *   vars[k]  = e_k - a_k^T (B_k + diag(c_k))^-1 a_k
+ * a,c,d: batch*n; B: batch*n*n (SPD, column-major, stride n*n); e, out: batch scalars. No input is modified
+ * and the inverse is never written to memory.
+ */
+int matinv_mean_batched(int dtype, int n, const void *dAs, const void *dBs, const void *dCs, const void *dDs,
+                        void *dMeans, size_t batch, int *dInfo, void *stream);
+int matinv_variance_batched(int dtype, int n, const void *dAs, const void *dBs, const void *dCs, const void *dEs,
+                            void *dVars, size_t batch, int *dInfo, void *stream);
+
+/* Host-pointer convenience used by the reference-named *_gpu wrappers: allocate, H2D, invert, D2H, free.
+ * `info` is an optional host int[batch]. Synchronous. */
+int matinv_inverse_batched_host(int algo, int dtype, int n, const void *hA, void *hAinv, size_t batch, int *info);
+
+const char *matinv_last_error(void);
+int matinv_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

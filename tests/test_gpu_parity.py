@@ -1,0 +1,318 @@
+"""Parity tests proper: HIP path (through the C ABI of libmatinv_hip.so) vs the CPU oracle on the same inputs,
+vs the committed golden vectors, and -- at BASELINE.json's full sizes -- through size-independent properties.
+
+Tolerances (BASELINE.json north_star "max element-wise rel. error < 1e-10"):
+  fp64 GPU vs fp64 oracle : max |x-y| / max(|y|, 1e-3*max|Y|) < 1e-10        (rel_err below)
+  fp32 GPU vs fp64 oracle : ||X-Y||_F / ||Y||_F < 1e-5 * cond
+  vs 4-digit reference goldens : sum|err| per matrix at the rounding floor (< 5e-4), means/variances < 5e-5
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import as_mats, general_batch, pkg, read_ref, rel_err, spd_batch
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+api = pkg("api")
+GJ, CH = api.ALGO_GAUSS_JORDAN, api.ALGO_CHOLESKY
+FAMILIES = {"auto": api.KERNEL_AUTO, "lds": api.KERNEL_LDS, "rowlane": api.KERNEL_ROWLANE, "tile": api.KERNEL_TILE}
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def gpu_inverse(a_np, n, algo=GJ, kernel=api.KERNEL_AUTO, want_info=False):
+    a = dev(a_np)
+    batch = a.numel() // (n * n)
+    info = torch.full((max(batch, 1),), -7, dtype=torch.int32, device="cuda")
+    out = api.inverse_batched(a, n, algo, info=info, kernel=kernel, batch=batch)
+    torch.cuda.synchronize()
+    assert torch.equal(a.cpu(), torch.from_numpy(np.ascontiguousarray(a_np))), "input batch was modified"
+    res = out.cpu().numpy()
+    return (res, info[:batch].cpu().numpy()) if want_info else res
+
+
+def family_or_skip(name, algo, dtype, n):
+    k = FAMILIES[name]
+    if k == api.KERNEL_AUTO:
+        return k
+    lib = pkg("_lib")
+    probe = torch.zeros(n * n, dtype=dtype, device="cuda") + torch.eye(n, dtype=dtype, device="cuda").reshape(-1)
+    try:
+        api.inverse_batched(probe, n, algo, kernel=k, batch=1)
+    except lib.MatinvError as e:
+        if e.code == lib.ERR_UNSUPPORTED:
+            pytest.skip(f"{name} family does not serve n={n}")
+        raise
+    return k
+
+
+SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 128]
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("n", SIZES)
+def test_gj_spd_fp64_vs_oracle(n, family):
+    k = family_or_skip(family, GJ, torch.float64, n)
+    a = spd_batch(n, 37, seed=n)
+    want, info = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT)
+    assert not info.any()
+    got, ginfo = gpu_inverse(a, n, GJ, k, want_info=True)
+    assert not ginfo.any()
+    assert rel_err(got, want, n) < 1e-10
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 16, 19, 32, 48, 64, 128])
+def test_gj_general_needs_pivoting_fp64(n, family):
+    """U(0,1) non-symmetric matrices (like tests/square_5_*): correct only with row pivoting."""
+    k = family_or_skip(family, GJ, torch.float64, n)
+    a = general_batch(n, 21, seed=1000 + n)
+    want, info = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT)
+    assert not info.any()
+    cond = max(np.linalg.cond(m) for m in as_mats(a, n))
+    got = gpu_inverse(a, n, GJ, k)
+    assert rel_err(got, want, n) < max(1e-10, 1e-15 * cond * n)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_cholesky_spd_fp64_vs_oracle(n):
+    a = spd_batch(n, 19, seed=50 + n)
+    want, info = oracle.inverse_batched(a, n, oracle.ALGO_CHOLESKY)
+    assert not info.any()
+    got, ginfo = gpu_inverse(a, n, CH, want_info=True)
+    assert not ginfo.any()
+    assert rel_err(got, want, n) < 1e-10
+    g = as_mats(got, n)
+    assert np.array_equal(g, g.transpose(0, 2, 1)) or rel_err(g.transpose(0, 2, 1).reshape(-1), got, n) < 1e-14
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("d,n", [("inverse_100_8x8", 8), ("inverse_100_16x16", 16), ("inverse_32_32x32", 32),
+                                 ("inverse_12_64x64", 64)])
+def test_reference_fixtures_and_goldens(d, n, family, gold):
+    k = family_or_skip(family, GJ, torch.float64, n)
+    a, cnt, _, _ = read_ref(f"{d}/a.mats")
+    got = gpu_inverse(a, n, GJ, k)
+    assert rel_err(got, gold[f"{d}/gj"], n) < 1e-10
+    got_c = gpu_inverse(a, n, CH)
+    assert rel_err(got_c, gold[f"{d}/chol"], n) < 1e-10
+    if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "ref", d, "aInv.mats")):
+        g, _, _, _ = read_ref(f"{d}/aInv.mats")  # the reference's own 4-digit MATLAB golden
+        for x in (got, got_c):
+            assert np.abs(x - g).sum() / cnt < 5e-4  # inverse_bench's error metric (inverse_bench.c:49-51,58)
+
+
+@pytest.mark.parametrize("f,n", [("square_5_8_8", 8), ("square_5_16_16", 16), ("square_5_32_32", 32),
+                                 ("square_3_64_64", 64), ("square_1_128_128", 128), ("batch_3", 3)])
+def test_square_fixtures_pivoting(f, n, gold):
+    a, _, _, _ = read_ref(f + ".mats")
+    assert rel_err(gpu_inverse(a, n, GJ), gold[f + "/gj"], n) < 1e-10
+
+
+def test_simplemean_cholesky_golden(gold):
+    a, _, _, n = read_ref("simpleMean/chol.mats")
+    g, _, _, _ = read_ref("simpleMean/cholinv.mats")
+    got = gpu_inverse(a, n, CH)
+    assert np.abs(got - g).max() < 1e-5
+    assert rel_err(got, gold["simpleMean/chol"], n) < 1e-9  # cond ~1185
+
+
+@pytest.mark.parametrize("n", [3, 8, 16, 32, 64])
+def test_singular_and_not_spd_report_info(n):
+    a = spd_batch(n, 8, seed=3).reshape(8, n, n)
+    a[2, 1, :] = a[2, 0, :] * 2.0  # column 1 = 2 * column 0 (memory is [k, col, row])
+    a[5] = 0.0
+    got, info = gpu_inverse(a.reshape(-1), n, GJ, want_info=True)
+    assert info[2] != 0 and info[5] == 1
+    assert (info[[0, 1, 3, 4, 6, 7]] == 0).all()
+    assert np.isnan(as_mats(got, n)[5]).all()
+    want, _ = oracle.inverse_batched(a.reshape(-1), n, oracle.ALGO_GJ_PIVOT)
+    ok = [0, 1, 3, 4, 6, 7]
+    assert rel_err(as_mats(got, n)[ok].reshape(-1), as_mats(want, n)[ok].reshape(-1), n) < 1e-10
+    b = spd_batch(n, 4, seed=4).reshape(4, n, n)
+    b[1, n - 1, n - 1] = -1.0
+    got, info = gpu_inverse(b.reshape(-1), n, CH, want_info=True)
+    _, oinfo = oracle.inverse_batched(b.reshape(-1), n, oracle.ALGO_CHOLESKY)
+    assert info.tolist() == oinfo.tolist() and info[1] == n
+    assert np.isnan(as_mats(got, n)[1]).all()
+
+
+def test_empty_and_single_batch():
+    e = torch.empty(0, dtype=torch.float64, device="cuda")
+    out = api.inverse_batched(e, 8, GJ, batch=0)
+    assert out.numel() == 0
+    a = spd_batch(16, 1, seed=9)
+    assert rel_err(gpu_inverse(a, 16), oracle.inverse_batched(a, 16)[0], 16) < 1e-10
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64, 128])
+def test_fp32_vs_fp64_oracle(n, family):
+    k = family_or_skip(family, GJ, torch.float32, n)
+    a = spd_batch(n, 16, seed=n)
+    want, _ = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT)
+    cond = max(np.linalg.cond(m) for m in as_mats(a, n))
+    for algo in (GJ, CH):
+        got = gpu_inverse(a.astype(np.float32), n, algo, k if algo == GJ else api.KERNEL_AUTO).astype(np.float64)
+        x, y = got.reshape(-1, n * n), want.reshape(-1, n * n)
+        fro = np.linalg.norm(x - y, axis=1) / np.linalg.norm(y, axis=1)
+        assert fro.max() < 1e-5 * cond
+
+
+def test_strided_batch_and_in_place():
+    n, batch, stride = 16, 9, 16 * 16 + 40
+    a = spd_batch(n, batch, seed=11).reshape(batch, n * n)
+    buf = np.full((batch, stride), 123.0)
+    buf[:, : n * n] = a
+    d_in = dev(buf.reshape(-1))
+    d_out = torch.full_like(d_in, -5.0)
+    api.inverse_batched(d_in, n, GJ, out=d_out, batch=batch, stride=stride)
+    res = d_out.cpu().numpy().reshape(batch, stride)
+    want, _ = oracle.inverse_batched(a.reshape(-1), n)
+    assert rel_err(res[:, : n * n].reshape(-1), want, n) < 1e-10
+    assert (res[:, n * n:] == -5.0).all(), "padding between matrices was written"
+    api.inverse_batched(d_in, n, GJ, out=d_in, batch=batch, stride=stride)  # exact aliasing is allowed
+    assert rel_err(d_in.cpu().numpy().reshape(batch, stride)[:, : n * n].reshape(-1), want, n) < 1e-10
+
+
+# ------------------------------------------------------------------ reference-named entry points (C symbols)
+@pytest.mark.parametrize("name", ["inverse_gauss_batched_gpu", "inverse_lu_cuda_batched_gpu",
+                                  "inverse_cholesky_batched_gpu", "inverse_cholesky_mm_batched_gpu",
+                                  "inverse_cholesky_mm2_batched_gpu", "inverse_cholesky_stride_batched_gpu"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_reference_host_pointer_family(name, dtype):
+    """inverse_bench's call sites (src/inverse_bench.c:144,168,191,214): host arrays in, host arrays out."""
+    n, batch = 32, 50
+    a = spd_batch(n, batch, seed=21).astype(dtype)
+    keep = a.copy()
+    out = np.zeros_like(a)
+    getattr(api, name)(n, a, out, batch)
+    assert np.array_equal(a, keep), "As must not be clobbered (the reference's Cholesky paths do, :442)"
+    want, _ = oracle.inverse_batched(keep.astype(np.float64), n)
+    assert rel_err(out.astype(np.float64), want, n) < (1e-10 if dtype == np.float64 else 1e-4)
+
+
+def _table(ptrs):
+    arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
+    return arr
+
+
+@pytest.mark.parametrize("uniform", [True, False])
+def test_reference_device_table_family(uniform):
+    """gauss_bench's dispatch point (src/gauss_bench.cu:77): host tables of device pointers, async on stream 0."""
+    n, batch = 16, 12
+    L = pkg("_lib").lib()
+    a = spd_batch(n, batch, seed=31)
+    pitch = n * n + (24 if uniform else 0)
+    d_in = torch.zeros(batch * (n * n + 64), dtype=torch.float64, device="cuda")
+    d_out = torch.zeros_like(d_in)
+    offs = [i * pitch for i in range(batch)] if uniform else [((i * 7) % batch) * (n * n + 64) for i in range(batch)]
+    for i, o in enumerate(offs):
+        d_in[o:o + n * n] = torch.from_numpy(a[i * n * n:(i + 1) * n * n]).cuda()
+    tin = _table([d_in.data_ptr() + 8 * o for o in offs])
+    tout = _table([d_out.data_ptr() + 8 * o for o in offs])
+    want, _ = oracle.inverse_batched(a, n)
+    torch.cuda.synchronize()
+    for name in ("inverse_gauss_batched_device", "inverse_lu_cuda_batched_device", "inverse_cholesky_batched_device",
+                 "inverse_cholesky_mm_batched_device", "inverse_cholesky_mm2_batched_device"):
+        d_out.zero_()
+        torch.cuda.synchronize()
+        getattr(L, name)(None, n, tin, tout, batch)
+        torch.cuda.synchronize()
+        res = d_out.cpu().numpy()
+        got = np.concatenate([res[o:o + n * n] for o in offs])
+        assert rel_err(got, want, n) < 1e-10, name
+
+
+def test_cholesky_subphase_entry_points():
+    """decompose / inverse_upper / multiply_upper (inverse_gpu.h:15-24): in place, lower triangle, upper zeroed."""
+    n, batch = 24, 6
+    L = pkg("_lib").lib()
+    a = spd_batch(n, batch, seed=41)
+    d = dev(a)
+    tab = _table([d.data_ptr() + 8 * i * n * n for i in range(batch)])
+    L.decompose_cholesky_batched_device(None, n, tab, tab, batch)
+    torch.cuda.synchronize()
+    Lf = as_mats(d.cpu().numpy(), n)
+    assert np.allclose(np.triu(Lf, 1), 0)
+    A = as_mats(a, n)
+    assert np.abs(Lf @ Lf.transpose(0, 2, 1) - A).max() < 1e-12 * n * np.abs(A).max()
+    L.inverse_upper_stride_batched_device(None, n, tab, tab, batch)
+    torch.cuda.synchronize()
+    Li = as_mats(d.cpu().numpy(), n)
+    assert np.abs(Li @ Lf - np.eye(n)).max() < 1e-12
+    L.multiply_upper_stride_batched_device(None, n, tab, tab, batch)
+    torch.cuda.synchronize()
+    want, _ = oracle.inverse_batched(a, n, oracle.ALGO_CHOLESKY)
+    assert rel_err(d.cpu().numpy(), want, n) < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------- pipeline
+@pytest.mark.parametrize("d,n", [("gaussian_100_8x8", 8), ("gaussian_100_16x16", 16), ("gaussian_32_32x32", 32),
+                                 ("gaussian_12_64x64", 64)])
+def test_pipeline_fixtures(d, n, gold):
+    r = {f: read_ref(f"{d}/{f}.mats")[0] for f in ("a", "b", "c", "d", "e", "means", "variances")}
+    t = {k: dev(v) for k, v in r.items()}
+    keep_b = t["b"].clone()
+    means = api.calcluateMean(n, t["a"], t["b"], t["c"], t["d"])
+    var = api.calcluateVariance(n, t["a"], t["b"], t["c"], t["e"])
+    torch.cuda.synchronize()
+    assert torch.equal(keep_b, t["b"])
+    m, v = means.cpu().numpy(), var.cpu().numpy()
+    assert np.abs(m - gold[f"{d}/means"]).max() < 1e-10 * max(1.0, np.abs(m).max())
+    assert np.abs(v - gold[f"{d}/variances"]).max() < 1e-10 * max(1.0, np.abs(v).max())
+    assert np.abs(m - r["means"]).mean() < 5e-5       # the reference's 4-digit goldens
+    assert np.abs(v - r["variances"]).mean() < 5e-5
+
+
+@pytest.mark.parametrize("n", [1, 5, 16, 33, 64, 128])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pipeline_synthetic(n, dtype):
+    rng = np.random.default_rng(n)
+    batch = 23
+    B = spd_batch(n, batch, seed=n)
+    a, c, d_ = (rng.random(batch * n) for _ in range(3))
+    e = rng.random(batch)
+    wm = oracle.mean_batched(a, B, c, d_, n)
+    wv = oracle.variance_batched(a, B, c, e, n)
+    t = [dev(x.astype(dtype)) for x in (a, B, c, d_, e)]
+    m = api.calcluateMean(n, t[0], t[1], t[2], t[3]).cpu().numpy().astype(np.float64)
+    v = api.calcluateVariance(n, t[0], t[1], t[2], t[4]).cpu().numpy().astype(np.float64)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    assert np.abs(m - wm).max() < tol and np.abs(v - wv).max() < tol
+
+
+# ------------------------------------------------------------- full-size, size-independent properties
+@pytest.mark.parametrize("n,batch", [(16, 100_000), (64, 100_000)])
+@pytest.mark.parametrize("algo", [GJ, CH])
+def test_full_size_properties(n, batch, algo):
+    """BASELINE.json configs 2 and 3 at full size. The oracle would take minutes here, so check properties:
+    residual A*X = I, involution inv(inv(A)) = A, homogeneity inv(2A) = inv(A)/2 (exact in binary fp),
+    and spot-check 64 matrices against the oracle."""
+    g = torch.Generator(device="cuda").manual_seed(1234 + n)
+    r = torch.rand((batch, n, n), generator=g, dtype=torch.float64, device="cuda")
+    a = r + r.transpose(1, 2) + n * torch.eye(n, dtype=torch.float64, device="cuda")
+    del r
+    flat = a.reshape(-1)
+    info = torch.empty(batch, dtype=torch.int32, device="cuda")
+    x = api.inverse_batched(flat, n, algo, info=info)
+    assert int(info.abs().sum()) == 0
+    xm = x.view(batch, n, n)
+    eye = torch.eye(n, dtype=torch.float64, device="cuda")
+    res = (torch.bmm(a, xm) - eye).abs().amax()
+    assert float(res) < 1e-13 * n
+    back = api.inverse_batched(x, n, algo)
+    assert float((back.view(batch, n, n) - a).abs().amax() / a.abs().amax()) < 1e-12
+    half = api.inverse_batched(flat * 2.0, n, algo)
+    assert torch.equal(half * 2.0, x), "inv(2A) must equal inv(A)/2 bit for bit (power-of-two scaling)"
+    idx = torch.arange(0, batch, batch // 64, device="cuda")[:64]
+    sub = a[idx].reshape(-1).cpu().numpy()
+    want, _ = oracle.inverse_batched(sub, n, oracle.ALGO_GJ_PIVOT if algo == GJ else oracle.ALGO_CHOLESKY)
+    assert rel_err(xm[idx].reshape(-1).cpu().numpy(), want, n) < 1e-10
