@@ -49,11 +49,23 @@ def make_spd(n, batch, seed, device):
     return a.reshape(-1).contiguous()
 
 
+def usable_cores():
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
 def cpu_baseline(n, algo_name, target_seconds=12.0):
     """Oracle (oracle/liboracle.so, a C port of the reference's CPU algorithms) timed on this box's host cores,
     OpenMP schedule(dynamic,8) over the batch as src/inverse.c:79 of the reference. Bounded sample."""
     import oracle
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     algo = oracle.ALGO_GJ_PIVOT if algo_name == "gj" else oracle.ALGO_CHOLESKY
     rng = np.random.default_rng(0)
 

@@ -27,6 +27,10 @@ __device__ __forceinline__ float nan_of<float>() { return __int_as_float(0x7fc00
 // family cannot serve (n, dtype). All are asynchronous on `stream`.
 template <class T>
 hipError_t launch_gj_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+// pivoted LDS kernel over a device-side work list (count + indices), used as the fallback of the fast families
+template <class T>
+hipError_t launch_gj_lds_worklist(int n, BatchRef<const T> A, BatchRef<T> X, const int *work_count, const int *work_list,
+                                  int *info, hipStream_t stream);
 // phases: bit 0 factor, bit 1 triangular inverse, bit 2 L^-T L^-1 (7 = full inverse)
 template <class T>
 hipError_t launch_chol_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,

@@ -43,21 +43,18 @@ template <class T>
 __device__ __forceinline__ T absval(T v) { return v < 0 ? -v : v; }
 
 // ------------------------------------------------------------------------------------------------
+// One matrix, whole workgroup. Block-uniform control flow; ends with every LDS access retired
+// (callers that loop must __syncthreads() before the next matrix).
 template <class T>
-__global__ __launch_bounds__(LDS_THREADS) void matinv_gj_lds(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n)
+__device__ __forceinline__ void gj_lds_one(const T *A, T *X, int *info_slot, int n, unsigned char *smem_raw,
+                                           T *s_red_val, int *s_red_idx)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ld = lds_ld(n);
     T *a = reinterpret_cast<T *>(smem_raw);  // a[c*ld + r]
     T *mcol = a + (size_t)n * ld;            // multipliers of the current step
     T *prow = mcol + n;                      // pivot row of the current step
     int *piv = reinterpret_cast<int *>(prow + 2 * n);  // (prow + n .. prow + 2n is spare)
-    __shared__ T s_red_val[LDS_THREADS / 64];
-    __shared__ int s_red_idx[LDS_THREADS / 64];
 
-    const size_t k_mat = blockIdx.x;
-    const T *A = Ain.at(k_mat);
-    T *X = Xout.at(k_mat);
     const int t = threadIdx.x;
     const int tx = t & 63, ty = t >> 6;
 
@@ -89,7 +86,7 @@ __global__ __launch_bounds__(LDS_THREADS) void matinv_gj_lds(BatchRef<const T> A
             if (ob > best || (ob == best && oi < p)) { best = ob; p = oi; }
         }
         if (!(best > 0)) {  // zero or NaN column: singular (block-uniform)
-            if (info && t == 0) info[k_mat] = k + 1;
+            if (info_slot && t == 0) *info_slot = k + 1;
             fill_nan(X, n);
             return;
         }
@@ -119,10 +116,9 @@ __global__ __launch_bounds__(LDS_THREADS) void matinv_gj_lds(BatchRef<const T> A
         __syncthreads();
     }
     // 4. undo the row swaps as column swaps in reverse order: X[:, j] = a[:, src[j]]
-    int *src = piv;  // reuse: first turn the pivot list into the composite column source map
+    int *src = piv;  // the pivot list becomes the composite column source map
     if (t == 0) {
-        // mcol/prow are free now: use them as int scratch
-        int *s = reinterpret_cast<int *>(mcol);
+        int *s = reinterpret_cast<int *>(mcol);  // mcol/prow are free now
         for (int j = 0; j < n; ++j) s[j] = j;
         for (int k = n - 1; k >= 0; --k) {
             int p = piv[k];
@@ -135,7 +131,34 @@ __global__ __launch_bounds__(LDS_THREADS) void matinv_gj_lds(BatchRef<const T> A
         const int sc = src[c];
         for (int r = tx; r < n; r += 64) X[(size_t)c * n + r] = a[sc * ld + r];
     }
-    if (info && t == 0) info[k_mat] = 0;
+    if (info_slot && t == 0) *info_slot = 0;
+}
+
+template <class T>
+__global__ __launch_bounds__(LDS_THREADS) void matinv_gj_lds(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ T s_red_val[LDS_THREADS / 64];
+    __shared__ int s_red_idx[LDS_THREADS / 64];
+    const size_t k_mat = blockIdx.x;
+    gj_lds_one<T>(Ain.at(k_mat), Xout.at(k_mat), info ? info + k_mat : nullptr, n, smem_raw, s_red_val, s_red_idx);
+}
+
+// Same algorithm over a device-side work list (indices of matrices a register-resident fast path rejected):
+// a fixed small grid strides over work_list[0 .. *work_count). An empty list costs one near-empty launch.
+template <class T>
+__global__ __launch_bounds__(LDS_THREADS) void matinv_gj_lds_worklist(BatchRef<const T> Ain, BatchRef<T> Xout, int *info,
+                                                                      int n, const int *work_count, const int *work_list)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ T s_red_val[LDS_THREADS / 64];
+    __shared__ int s_red_idx[LDS_THREADS / 64];
+    const int count = *work_count;
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        const size_t k_mat = (size_t)work_list[i];
+        gj_lds_one<T>(Ain.at(k_mat), Xout.at(k_mat), info ? info + k_mat : nullptr, n, smem_raw, s_red_val, s_red_idx);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -325,6 +348,18 @@ hipError_t launch_gj_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch
     return hipGetLastError();
 }
 template <class T>
+hipError_t launch_gj_lds_worklist(int n, BatchRef<const T> A, BatchRef<T> X, const int *work_count, const int *work_list,
+                                  int *info, hipStream_t stream)
+{
+    if (!lds_family_supports<T>(n)) return hipErrorInvalidValue;
+    const size_t bytes = lds_bytes<T>(n);
+    hipError_t e = prepare_lds(matinv_gj_lds_worklist<T>, bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(matinv_gj_lds_worklist<T>, dim3(1024), dim3(LDS_THREADS), bytes, stream, A, X, info, n, work_count,
+                       work_list);
+    return hipGetLastError();
+}
+template <class T>
 hipError_t launch_chol_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
                            int phases)
 {
@@ -352,6 +387,8 @@ hipError_t launch_gp_lds(int n, const T *As, const T *Bs, const T *Cs, const T *
 }
 #define INST(T)                                                                                                        \
     template hipError_t launch_gj_lds<T>(int, BatchRef<const T>, BatchRef<T>, size_t, int *, hipStream_t);            \
+    template hipError_t launch_gj_lds_worklist<T>(int, BatchRef<const T>, BatchRef<T>, const int *, const int *,      \
+                                                  int *, hipStream_t);                                                \
     template hipError_t launch_chol_lds<T>(int, BatchRef<const T>, BatchRef<T>, size_t, int *, hipStream_t, int);     \
     template hipError_t launch_gp_lds<T>(int, const T *, const T *, const T *, const T *, const T *, T *, size_t,     \
                                          int *, hipStream_t);
