@@ -1,12 +1,314 @@
-// rowlane_kernels.hip -- placeholder until the register-resident small-n family lands.
+// rowlane_kernels.hip -- kernel family "ROWLANE": n <= 16, several matrices per wavefront, register resident.
+//
+// A wavefront holds 64/NP matrices (NP = 8 or 16 = n rounded up, identity padded): lane (g, i) owns row i of
+// matrix g, register c holds column c, so the load `a[c] = A[c*n + i]` is a coalesced 8*NP-byte segment per matrix
+// and consecutive matrices of the batch are adjacent in the wave. In-place Gauss-Jordan with partial (row) pivoting:
+//   * pivot search   = max-reduction of |a[k]| over the NP lanes of the matrix with DPP quad_perm / row_half_mirror /
+//                      row_mirror (no LDS), ballot + ctz for the pivot lane;
+//   * pivot row      = brought to lane k (ds_bpermute row swap, only when some matrix of the wave needs it -- never on
+//                      diagonally dominant input) and then broadcast with DPP row_newbcast:k straight into the FMA operand;
+//   * elimination    = NP fused multiply-adds per lane per step, multiplier lane-local.
+// Row swaps are undone as a column permutation folded into the store addresses.
+//
+// Replaces, for small n, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95 (pivotRow :17-45,
+// normalizeRow :47-57, transform_matrix :59-82) with one launch that touches HBM once per element.
 #include "common.hpp"
+
 namespace matinv {
-template <class T> bool rowlane_family_supports(int) { return false; }
+
+constexpr int ROWLANE_THREADS = 256;
+
+// DPP controls (LLVM AMDGPU DppCtrl encoding)
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15-i within a row of 16
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i within each half row
+constexpr int DPP_ROW_NEWBCAST = 0x150;    // + lane: broadcast that lane of each row of 16
+
+template <int NP, int K, class V>
+__device__ __forceinline__ V bcast_const(V v)
+{
+    // value of lane K of the matrix this lane belongs to
+    if (NP == 16) {
+        // every lane is written, so `old` is dead: pass a constant to avoid a tied copy
+        return __builtin_amdgcn_update_dpp(V(0), v, DPP_ROW_NEWBCAST + K, 0xf, 0xf, false);
+    } else {
+        // two matrices per DPP row: lanes 0-7 (banks 0,1) take lane K, lanes 8-15 (banks 2,3) take lane K+8
+        V t = __builtin_amdgcn_update_dpp(v, v, DPP_ROW_NEWBCAST + K, 0xf, 0x3, false);
+        return __builtin_amdgcn_update_dpp(t, v, DPP_ROW_NEWBCAST + K + 8, 0xf, 0xc, false);
+    }
+}
+
+// k comes from a fully unrolled loop: the switch folds to the single case
+template <int NP, class V>
+__device__ __forceinline__ V bcast_lane(V v, int k)
+{
+    switch (k) {
+    case 0: return bcast_const<NP, 0>(v);
+    case 1: return bcast_const<NP, 1>(v);
+    case 2: return bcast_const<NP, 2>(v);
+    case 3: return bcast_const<NP, 3>(v);
+    case 4: return bcast_const<NP, 4>(v);
+    case 5: return bcast_const<NP, 5>(v);
+    case 6: return bcast_const<NP, 6>(v);
+    case 7: return bcast_const<NP, 7>(v);
+    case 8: return bcast_const<16, 8>(v);
+    case 9: return bcast_const<16, 9>(v);
+    case 10: return bcast_const<16, 10>(v);
+    case 11: return bcast_const<16, 11>(v);
+    case 12: return bcast_const<16, 12>(v);
+    case 13: return bcast_const<16, 13>(v);
+    case 14: return bcast_const<16, 14>(v);
+    default: return bcast_const<16, 15>(v);
+    }
+}
+
+// One elimination step on the register-resident rows, as ONE asm block so the instruction order is fixed:
+//   for every column c != K:  a[c] += a_pivotrow[c] * negm      (v_fmac_*_dpp: the DPP row broadcast of lane K is
+//                                                                folded into the FMA operand -- hipcc does not form
+//                                                                this from __builtin_amdgcn_update_dpp)
+//   for every column c != K:  a[c] *= scale                      (1/pivot on the pivot row, 1.0 elsewhere)
+// The pivot row has negm = 0, so the broadcast always reads the UNSCALED pivot row. Hazards: the ISA wants 2 wait
+// states between a VALU write of a VGPR and a DPP read of it, and hipcc pads nothing inside or before an asm block:
+// the leading `s_nop 1` covers whatever VALU instruction the compiler scheduled last; inside the block a register is
+// DPP-read (first loop) strictly before it is written again (its own fmac, then the multiply loop).
+#define RL_FMAC16(T_, c) \
+    ".if %[k] != " #c "\n\tv_fmac_" T_ "_dpp %[a" #c "], %[a" #c "], %[m] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t.endif\n\t"
+// NP = 8: two matrices share a DPP row of 16 lanes. 64-bit DPP ignores bank_mask (measured on gfx950: both halves were
+// written), so the half-row selection is done with EXEC instead: lanes 0-7 of every row take lane K, then lanes 8-15
+// take lane K+8 (the source lane is always inside the enabled half).
+#define RL_FMAC8(T_, c, kk) \
+    ".if %[k] != " #c "\n\tv_fmac_" T_ "_dpp %[a" #c "], %[a" #c "], %[m] row_newbcast:%[" kk "] row_mask:0xf bank_mask:0xf\n\t.endif\n\t"
+#define RL_FMAC8_LO(T_, c) RL_FMAC8(T_, c, "k")
+#define RL_FMAC8_HI(T_, c) RL_FMAC8(T_, c, "k8")
+#define RL_STEP8(T_)                                                                                                  \
+    "s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, 0x00ff00ff\n\ts_mov_b32 exec_hi, 0x00ff00ff\n\ts_nop 1\n\t"          \
+    RL_8(RL_FMAC8_LO, T_)                                                                                             \
+    "s_mov_b32 exec_lo, 0xff00ff00\n\ts_mov_b32 exec_hi, 0xff00ff00\n\ts_nop 1\n\t"                                  \
+    RL_8(RL_FMAC8_HI, T_)                                                                                             \
+    "s_mov_b64 exec, %[sv]\n\t"                                                                                       \
+    RL_8(RL_MUL, T_)
+#define RL_MUL(T_, c) ".if %[k] != " #c "\n\tv_mul_" T_ " %[a" #c "], %[a" #c "], %[s]\n\t.endif\n\t"
+#define RL_8(M, T_) M(T_, 0) M(T_, 1) M(T_, 2) M(T_, 3) M(T_, 4) M(T_, 5) M(T_, 6) M(T_, 7)
+#define RL_16(M, T_) RL_8(M, T_) M(T_, 8) M(T_, 9) M(T_, 10) M(T_, 11) M(T_, 12) M(T_, 13) M(T_, 14) M(T_, 15)
+#define RL_OPS8 [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]), [a5] "+v"(a[5]), \
+                [a6] "+v"(a[6]), [a7] "+v"(a[7])
+#define RL_OPS16 RL_OPS8, [a8] "+v"(a[8]), [a9] "+v"(a[9]), [a10] "+v"(a[10]), [a11] "+v"(a[11]), [a12] "+v"(a[12]),  \
+                 [a13] "+v"(a[13]), [a14] "+v"(a[14]), [a15] "+v"(a[15])
+
+template <int K>
+__device__ __forceinline__ void elim_step_const(double (&a)[16], double negm, double scale)
+{
+    asm volatile("s_nop 1\n\t" RL_16(RL_FMAC16, "f64") RL_16(RL_MUL, "f64")
+                 : RL_OPS16 : [m] "v"(negm), [s] "v"(scale), [k] "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void elim_step_const(float (&a)[16], float negm, float scale)
+{
+    asm volatile("s_nop 1\n\t" RL_16(RL_FMAC16, "f32") RL_16(RL_MUL, "f32")
+                 : RL_OPS16 : [m] "v"(negm), [s] "v"(scale), [k] "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void elim_step_const(double (&a)[8], double negm, double scale)
+{
+    unsigned long long sv;
+    asm volatile(RL_STEP8("f64") : RL_OPS8, [sv] "=&s"(sv) : [m] "v"(negm), [s] "v"(scale), [k] "n"(K), [k8] "n"(K + 8));
+}
+template <int K>
+__device__ __forceinline__ void elim_step_const(float (&a)[8], float negm, float scale)
+{
+    unsigned long long sv;
+    asm volatile(RL_STEP8("f32") : RL_OPS8, [sv] "=&s"(sv) : [m] "v"(negm), [s] "v"(scale), [k] "n"(K), [k8] "n"(K + 8));
+}
+
 template <class T>
-hipError_t launch_gj_rowlane(int, BatchRef<const T>, BatchRef<T>, size_t, int *, hipStream_t) { return hipErrorInvalidValue; }
+__device__ __forceinline__ void elim_step(T (&a)[8], T negm, T scale, int k)
+{
+    switch (k) {
+    case 0: elim_step_const<0>(a, negm, scale); break;
+    case 1: elim_step_const<1>(a, negm, scale); break;
+    case 2: elim_step_const<2>(a, negm, scale); break;
+    case 3: elim_step_const<3>(a, negm, scale); break;
+    case 4: elim_step_const<4>(a, negm, scale); break;
+    case 5: elim_step_const<5>(a, negm, scale); break;
+    case 6: elim_step_const<6>(a, negm, scale); break;
+    default: elim_step_const<7>(a, negm, scale); break;
+    }
+}
+template <class T>
+__device__ __forceinline__ void elim_step(T (&a)[16], T negm, T scale, int k)
+{
+    switch (k) {
+    case 0: elim_step_const<0>(a, negm, scale); break;
+    case 1: elim_step_const<1>(a, negm, scale); break;
+    case 2: elim_step_const<2>(a, negm, scale); break;
+    case 3: elim_step_const<3>(a, negm, scale); break;
+    case 4: elim_step_const<4>(a, negm, scale); break;
+    case 5: elim_step_const<5>(a, negm, scale); break;
+    case 6: elim_step_const<6>(a, negm, scale); break;
+    case 7: elim_step_const<7>(a, negm, scale); break;
+    case 8: elim_step_const<8>(a, negm, scale); break;
+    case 9: elim_step_const<9>(a, negm, scale); break;
+    case 10: elim_step_const<10>(a, negm, scale); break;
+    case 11: elim_step_const<11>(a, negm, scale); break;
+    case 12: elim_step_const<12>(a, negm, scale); break;
+    case 13: elim_step_const<13>(a, negm, scale); break;
+    case 14: elim_step_const<14>(a, negm, scale); break;
+    default: elim_step_const<15>(a, negm, scale); break;
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+template <int NP>
+__device__ __forceinline__ unsigned group_max(unsigned v)
+{
+    v = max(v, dpp_u32<DPP_QUAD_XOR1>(v));
+    v = max(v, dpp_u32<DPP_QUAD_XOR2>(v));
+    v = max(v, dpp_u32<DPP_ROW_HALF_MIRROR>(v));
+    if (NP == 16) v = max(v, dpp_u32<DPP_ROW_MIRROR>(v));
+    return v;
+}
+
+// magnitude key: monotone in |v| (top 32 bits of the IEEE pattern; for fp64 ties within 2^-20 relative pick the lowest row)
+__device__ __forceinline__ unsigned mag_key(double v) { return (unsigned)(__double_as_longlong(v) >> 32) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned mag_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ bool key_not_finite(double, unsigned k) { return k >= 0x7ff00000u; }
+__device__ __forceinline__ bool key_not_finite(float, unsigned k) { return k >= 0x7f800000u; }
+
+__device__ __forceinline__ double recip(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ float recip(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(r, e, r);
+}
+
+template <class T, int NP, bool FULL>
+__global__ __launch_bounds__(ROWLANE_THREADS) void matinv_gj_rowlane(BatchRef<const T> Ain, BatchRef<T> Xout, int *info,
+                                                                     int n_rt, unsigned batch)
+{
+    constexpr int GPW = 64 / NP;  // matrices per wavefront
+    const int n = FULL ? NP : n_rt;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / NP, i = lane % NP;
+    const unsigned waves_per_block = ROWLANE_THREADS / 64;
+    const unsigned wave0 = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const unsigned wave_stride = gridDim.x * waves_per_block;
+    const unsigned n_waves = (batch + GPW - 1) / GPW;
+
+    for (unsigned w = wave0; w < n_waves; w += wave_stride) {
+        const unsigned mat = w * GPW + g;
+        const bool valid = mat < batch;
+        const T *A = Ain.at(valid ? mat : batch - 1);
+        T *X = Xout.at(valid ? mat : batch - 1);
+        const bool row_in = FULL || i < n;
+
+        T a[NP];
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+            a[c] = (valid && row_in && (FULL || c < n)) ? A[c * n + i] : ((i == c) ? (T)1 : (T)0);
+
+        int src = i;          // lane j: source column of output column j (composite of the undone row swaps)
+        int bad = 0;          // k+1 of the first step without a usable pivot
+        bool any_swap = false;  // wave-uniform
+
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            // 1. pivot search in column k over rows >= k of this lane's matrix
+            const unsigned key = (i >= k) ? mag_key(a[k]) : 0u;
+            const unsigned mx = group_max<NP>(key);
+            const bool is_max = (key == mx) && (i >= k);
+            const unsigned long long vote = __ballot(is_max);
+            const unsigned gbits = (unsigned)(vote >> (g * NP)) & ((1u << NP) - 1u);
+            const int p = __builtin_ctz(gbits | 0x80000000u);  // lowest row attaining the maximum
+            const bool singular = (mx == 0u) || key_not_finite(T(0), mx);
+            if (singular && bad == 0) bad = k + 1;
+            const bool need_swap = (p != k) && !singular;
+            if (__any(need_swap)) {
+                any_swap = true;
+                const int partner = need_swap ? ((i == k) ? p : (i == p) ? k : i) : i;
+                const int from = g * NP + partner;
+#pragma unroll
+                for (int c = 0; c < NP; ++c) a[c] = __shfl(a[c], from);
+                if (need_swap) src = (src == k) ? p : (src == p) ? k : src;
+            }
+            // 2. normalise + eliminate. m = a[i][k] / pivot (0 on the pivot row, which is scaled instead)
+            const T piv = bcast_lane<NP>(a[k], k);
+            const T inv = recip(piv);
+            const T negm = (i == k) ? (T)0 : -(a[k] * inv);
+            const T scale = (i == k) ? inv : (T)1;
+            elim_step(a, negm, scale, k);
+            a[k] = (i == k) ? inv : negm;
+        }
+
+        // 3. store; undo the row swaps as a column permutation of the addresses
+        const bool fail = bad != 0;
+        if (!any_swap) {
+#pragma unroll
+            for (int c = 0; c < NP; ++c)
+                if (valid && row_in && (FULL || c < n)) X[c * n + i] = fail ? nan_of<T>() : a[c];
+        } else {
+            // lane j pushes j to lane src(j): afterwards lane c holds the output column of register c
+            const int dst = __builtin_amdgcn_ds_permute((g * NP + src) << 2, i);
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                const int dcol = bcast_lane<NP>(dst, c);
+                if (valid && row_in && (FULL || c < n)) X[dcol * n + i] = fail ? nan_of<T>() : a[c];
+            }
+        }
+        if (info && valid && i == 0) info[mat] = bad;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class T>
+bool rowlane_family_supports(int n) { return n >= 1 && n <= 16; }
 template bool rowlane_family_supports<double>(int);
 template bool rowlane_family_supports<float>(int);
+
+template <class T, int NP, bool FULL>
+static hipError_t launch_one(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    const unsigned gpw = 64 / NP;
+    const size_t waves = (batch + gpw - 1) / gpw;
+    const size_t blocks = (waves + ROWLANE_THREADS / 64 - 1) / (ROWLANE_THREADS / 64);
+    const unsigned grid = (unsigned)(blocks < 256u * 8u * 2u ? blocks : 256u * 8u * 2u);
+    hipLaunchKernelGGL((matinv_gj_rowlane<T, NP, FULL>), dim3(grid), dim3(ROWLANE_THREADS), 0, stream, A, X, info, n,
+                       (unsigned)batch);
+    return hipGetLastError();
+}
+
+template <class T>
+hipError_t launch_gj_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    if (!rowlane_family_supports<T>(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    if (n == 16) return launch_one<T, 16, true>(n, A, X, batch, info, stream);
+    if (n == 8) return launch_one<T, 8, true>(n, A, X, batch, info, stream);
+    if (n < 8) return launch_one<T, 8, false>(n, A, X, batch, info, stream);
+    return launch_one<T, 16, false>(n, A, X, batch, info, stream);
+}
 template hipError_t launch_gj_rowlane<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
 template hipError_t launch_gj_rowlane<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
-const char *name_gj_rowlane(bool, int) { return ""; }
+
+const char *name_gj_rowlane(bool f64, int n)
+{
+    if (n == 16) return f64 ? "matinv_gj_rowlane<double, 16, true>" : "matinv_gj_rowlane<float, 16, true>";
+    if (n == 8) return f64 ? "matinv_gj_rowlane<double, 8, true>" : "matinv_gj_rowlane<float, 8, true>";
+    if (n < 8) return f64 ? "matinv_gj_rowlane<double, 8, false>" : "matinv_gj_rowlane<float, 8, false>";
+    return f64 ? "matinv_gj_rowlane<double, 16, false>" : "matinv_gj_rowlane<float, 16, false>";
 }
+
+}  // namespace matinv
