@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmatinv_hip.so")
+LIB_PATH = os.environ.get("MATINV_LIB", os.path.join(_HERE, "libmatinv_hip.so"))  # override: profiling builds only
 
 # include/matinv.h enums
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4

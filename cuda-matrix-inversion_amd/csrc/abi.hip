@@ -58,6 +58,8 @@ int select_auto(int algo, int n)
     if (algo == MATINV_ALGO_GAUSS_JORDAN) {
         if (rowlane_family_supports<T>(n)) return MATINV_KERNEL_ROWLANE;
         if (tile_family_supports<T>(n)) return MATINV_KERNEL_TILE;
+    } else if (spd_tile_supports<T>(n)) {
+        return MATINV_KERNEL_TILE;
     }
     if (lds_family_supports<T>(n)) return MATINV_KERNEL_LDS;
     return MATINV_ERR_UNSUPPORTED;
@@ -75,7 +77,9 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
     int rc = check_device();
     if (rc) return rc;
     if (kernel == MATINV_KERNEL_AUTO) {
-        kernel = select_auto<T>(algo, n);
+        // the Cholesky sub-phase entry points (factor only, ...) exist in the LDS family only
+        kernel = (algo == MATINV_ALGO_CHOLESKY && chol_phases != 7 && lds_family_supports<T>(n)) ? (int)MATINV_KERNEL_LDS
+                                                                                                 : select_auto<T>(algo, n);
         if (kernel < 0)
             return fail(MATINV_ERR_UNSUPPORTED, "n=%d exceeds every kernel family built in (LDS family limit)", n);
     }
@@ -92,8 +96,14 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
         e = launch_gj_rowlane<T>(n, A, X, batch, dInfo, stream);
         break;
     case MATINV_KERNEL_TILE:
-        if (algo != MATINV_ALGO_GAUSS_JORDAN || !tile_family_supports<T>(n))
-            return fail(MATINV_ERR_UNSUPPORTED, "tile family serves f64 Gauss-Jordan with 16 < n <= 64 only (n=%d)", n);
+        if (algo == MATINV_ALGO_CHOLESKY) {
+            if (!spd_tile_supports<T>(n) || chol_phases != 7)
+                return fail(MATINV_ERR_UNSUPPORTED, "tile family serves the full f64 SPD inverse with n <= 64 only (n=%d)", n);
+            e = launch_spd_tile<T>(n, A, X, batch, dInfo, stream);
+            break;
+        }
+        if (!tile_family_supports<T>(n))
+            return fail(MATINV_ERR_UNSUPPORTED, "tile family serves f64 Gauss-Jordan with n <= 64 only (n=%d)", n);
         e = launch_gj_tile<T>(n, A, X, batch, dInfo, stream);
         break;
     default:
@@ -305,7 +315,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     switch (kernel) {
     case MATINV_KERNEL_LDS: return algo == MATINV_ALGO_CHOLESKY ? name_chol_lds(f64) : name_gj_lds(f64);
     case MATINV_KERNEL_ROWLANE: return name_gj_rowlane(f64, n);
-    case MATINV_KERNEL_TILE: return name_gj_tile(f64, n);
+    case MATINV_KERNEL_TILE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_tile(f64, n) : name_gj_tile(f64, n);
     default: return "";
     }
 }

@@ -31,6 +31,9 @@ hipError_t launch_gj_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch
 template <class T>
 hipError_t launch_gj_lds_worklist(int n, BatchRef<const T> A, BatchRef<T> X, const int *work_count, const int *work_list,
                                   int *info, hipStream_t stream);
+template <class T>
+hipError_t launch_chol_lds_worklist(int n, BatchRef<const T> A, BatchRef<T> X, const int *work_count,
+                                    const int *work_list, int *info, hipStream_t stream);
 // phases: bit 0 factor, bit 1 triangular inverse, bit 2 L^-T L^-1 (7 = full inverse)
 template <class T>
 hipError_t launch_chol_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
@@ -51,6 +54,12 @@ template <class T>
 hipError_t launch_gj_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 template <class T>
 bool tile_family_supports(int n);
+// SPD (symmetric blocked sweep) on the tile layout, f64, n <= 64
+template <class T>
+hipError_t launch_spd_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+bool spd_tile_supports(int n);
+const char *name_spd_tile(bool f64, int n);
 
 const char *name_gj_rowlane(bool f64, int n);
 const char *name_gj_tile(bool f64, int n);

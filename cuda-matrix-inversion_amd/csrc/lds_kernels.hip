@@ -219,17 +219,11 @@ enum { CHOL_PHASE_FACTOR = 1, CHOL_PHASE_TRINV = 2, CHOL_PHASE_MULT = 4, CHOL_PH
 // otherwise the lower triangle (L or L^-1) with the strict upper triangle zeroed, as the reference's
 // decompose kernels do (src/inverse_cholesky_gpu.cu:268-270). Ain may equal Xout (in place).
 template <class T>
-__global__ __launch_bounds__(LDS_THREADS) void matinv_chol_lds(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n,
-                                                               int phases)
+__device__ __forceinline__ void chol_lds_one(const T *A, T *X, int *info_slot, int n, int phases, unsigned char *smem_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ld = lds_ld(n);
     T *a = reinterpret_cast<T *>(smem_raw);  // lower triangle: A, then L, then L^-1
     T *vec = a + (size_t)n * ld;
-
-    const size_t k_mat = blockIdx.x;
-    const T *A = Ain.at(k_mat);
-    T *X = Xout.at(k_mat);
     const int t = threadIdx.x;
     const int tx = t & 63, ty = t >> 6;
 
@@ -240,7 +234,7 @@ __global__ __launch_bounds__(LDS_THREADS) void matinv_chol_lds(BatchRef<const T>
     if (phases & CHOL_PHASE_FACTOR) {
         const int bad = chol_factor_lds(a, ld, n);
         if (bad) {
-            if (info && t == 0) info[k_mat] = bad;
+            if (info_slot && t == 0) *info_slot = bad;
             fill_nan(X, n);
             return;
         }
@@ -258,7 +252,31 @@ __global__ __launch_bounds__(LDS_THREADS) void matinv_chol_lds(BatchRef<const T>
         for (int c = ty; c < n; c += LDS_THREADS / 64)
             for (int r = tx; r < n; r += 64) X[(size_t)c * n + r] = (r >= c) ? a[c * ld + r] : (T)0;
     }
-    if (info && t == 0) info[k_mat] = 0;
+    if (info_slot && t == 0) *info_slot = 0;
+}
+
+template <class T>
+__global__ __launch_bounds__(LDS_THREADS) void matinv_chol_lds(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n,
+                                                               int phases)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const size_t k_mat = blockIdx.x;
+    chol_lds_one<T>(Ain.at(k_mat), Xout.at(k_mat), info ? info + k_mat : nullptr, n, phases, smem_raw);
+}
+
+// Full Cholesky inverse over a device-side work list (fallback of the register-resident SPD fast path).
+template <class T>
+__global__ __launch_bounds__(LDS_THREADS) void matinv_chol_lds_worklist(BatchRef<const T> Ain, BatchRef<T> Xout, int *info,
+                                                                        int n, const int *work_count,
+                                                                        const int *work_list)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int count = *work_count;
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        const size_t k_mat = (size_t)work_list[i];
+        chol_lds_one<T>(Ain.at(k_mat), Xout.at(k_mat), info ? info + k_mat : nullptr, n, CHOL_PHASE_ALL, smem_raw);
+        __syncthreads();
+    }
 }
 
 // Fused Gaussian-process scalar: out = u^T (B + diag c)^-1 w  (mean: u=a, w=d)  or  e - a^T (B+diag c)^-1 a.
@@ -360,6 +378,18 @@ hipError_t launch_gj_lds_worklist(int n, BatchRef<const T> A, BatchRef<T> X, con
     return hipGetLastError();
 }
 template <class T>
+hipError_t launch_chol_lds_worklist(int n, BatchRef<const T> A, BatchRef<T> X, const int *work_count,
+                                    const int *work_list, int *info, hipStream_t stream)
+{
+    if (!lds_family_supports<T>(n)) return hipErrorInvalidValue;
+    const size_t bytes = lds_bytes<T>(n);
+    hipError_t e = prepare_lds(matinv_chol_lds_worklist<T>, bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(matinv_chol_lds_worklist<T>, dim3(1024), dim3(LDS_THREADS), bytes, stream, A, X, info, n,
+                       work_count, work_list);
+    return hipGetLastError();
+}
+template <class T>
 hipError_t launch_chol_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
                            int phases)
 {
@@ -390,6 +420,8 @@ hipError_t launch_gp_lds(int n, const T *As, const T *Bs, const T *Cs, const T *
     template hipError_t launch_gj_lds_worklist<T>(int, BatchRef<const T>, BatchRef<T>, const int *, const int *,      \
                                                   int *, hipStream_t);                                                \
     template hipError_t launch_chol_lds<T>(int, BatchRef<const T>, BatchRef<T>, size_t, int *, hipStream_t, int);     \
+    template hipError_t launch_chol_lds_worklist<T>(int, BatchRef<const T>, BatchRef<T>, const int *, const int *,    \
+                                                    int *, hipStream_t);                                              \
     template hipError_t launch_gp_lds<T>(int, const T *, const T *, const T *, const T *, const T *, T *, size_t,     \
                                          int *, hipStream_t);
 INST(double)

@@ -38,6 +38,7 @@
 namespace matinv {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr double TILE_TAU = 4.0;
 
@@ -83,7 +84,16 @@ __device__ __forceinline__ void panel_to_lds(double *panel, const v4d (&acc)[NT]
 //       aop[ti] = Aop[16ti + c][q] and update the acceptance flag. Split into NSTAGE pieces of roughly equal
 //       VALU/LDS work so the look-ahead loop can issue one MFMA of the CURRENT block step between two pieces of the
 //       NEXT step's panel (hardware issues in order: MFMA, ~64 cycles of VALU, MFMA, ... keeps both pipes busy).
-template <int NT>
+// !(v > 0) accumulated like note_fail: SPD mode rejects a non-positive (or NaN) pivot
+__device__ __forceinline__ void note_nonpositive(unsigned long long &bad, double v)
+{
+    asm volatile("v_cmp_ngt_f64_e64 vcc, %1, 0\n\ts_or_b64 %0, %0, vcc" : "+s"(bad) : "v"(v) : "vcc");
+}
+
+// SPD = true: symmetric blocked sweep for SPD input (see matinv_spd_tile_f64). Same arithmetic for D^-1 and Aop; the
+// acceptance test becomes "all four pivots of D positive" (they are the squares of the Cholesky diagonal), and the
+// stage of tile row ti also returns bsym[ti] = P[16ti + c][q], the B operand by symmetry (W[K, J] = W[J, K]^T).
+template <int NT, bool SPD = false>
 struct PanelSolve {
     static constexpr int NSTAGE = 6 + NT;
     double d[4][4];
@@ -92,6 +102,12 @@ struct PanelSolve {
 
     __device__ __forceinline__ void stage(int s, const double *panel, int kb, int q, int c, double (&aop)[NT],
                                           unsigned long long &bad)
+    {
+        double unused[NT];
+        stage(s, panel, kb, q, c, aop, unused, bad);
+    }
+    __device__ __forceinline__ void stage(int s, const double *panel, int kb, int q, int c, double (&aop)[NT],
+                                          double (&bsym)[NT], unsigned long long &bad)
     {
         const int tK = kb >> 2, c0 = 4 * (kb & 3), K0 = 4 * kb;
         const bool panel_lane = (c >= c0) && (c < c0 + 4);
@@ -120,8 +136,13 @@ struct PanelSolve {
             u33 = __builtin_fma(-l32, u23, b33);
         } else if (s == 3) {
             r3 = fast_rcp(u33);
-            note_fail(bad, l10), note_fail(bad, l20), note_fail(bad, l30);
-            note_fail(bad, l21), note_fail(bad, l31), note_fail(bad, l32);
+            if (SPD) {
+                note_nonpositive(bad, d[0][0]), note_nonpositive(bad, u11);
+                note_nonpositive(bad, u22), note_nonpositive(bad, u33);
+            } else {
+                note_fail(bad, l10), note_fail(bad, l20), note_fail(bad, l30);
+                note_fail(bad, l21), note_fail(bad, l31), note_fail(bad, l32);
+            }
             // a zero / non-finite last pivot needs no test of its own: r3 = inf/NaN makes x, hence every Aop entry
             // outside the pivot rows (0 * inf = NaN included), fail the test in the last stages
         } else if (s == 4) {
@@ -146,12 +167,16 @@ struct PanelSolve {
                 const int m = c - c0;
                 const double x01 = (m & 1) ? x1 : x0, x23 = (m & 1) ? x3 : x2;
                 const double xm = (m & 2) ? x23 : x01;
-                note_fail(bad, panel_lane ? 0.0 : v);
+                if (!SPD) note_fail(bad, panel_lane ? 0.0 : v);
                 v = panel_lane ? xm : v;
             } else {
-                note_fail(bad, v);
+                if (!SPD) note_fail(bad, v);
             }
             aop[ti] = v;
+            if (SPD) {
+                const double w01 = (q & 1) ? w1 : w0, w23 = (q & 1) ? w3 : w2;
+                bsym[ti] = (q & 2) ? w23 : w01;
+            }
         }
     }
 };
@@ -196,6 +221,14 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
 {
     constexpr int N = 16 * NT;
     constexpr int NKB = 4 * NT;
+    // PAIRED: 16-byte global accesses. The labels (tile, register, lane) -> (matrix row, matrix column) are ours to
+    // choose as long as pivot block kb uses the same index set for its rows (tile row kb/4, register kb%4, q = 0..3)
+    // and columns (tile column kb/4, lanes c = 4(kb%4)..+3). With
+    //     row(ti, r, q) = 32(ti>>1) + 8r + 2q + (ti&1),    col(tj, c) = 32(tj>>1) + 2c + (tj&1)
+    // lane c of the tile-column pair (2u, 2u+1) owns the ADJACENT columns 32u+2c, 32u+2c+1 of its row, i.e. one
+    // 16-byte access feeds two tiles and a 16-lane group covers 256 contiguous bytes. Nothing else in the kernel
+    // depends on the relabelling (a symmetric permutation of the matrix: inv(P A P^T) = P inv(A) P^T).
+    constexpr bool PAIRED = FULL && (NT % 2 == 0);
     const int n = FULL ? N : n_rt;
     __shared__ __attribute__((aligned(16))) double panel[N * 4];  // [row][4 pivot columns]
     const int l = threadIdx.x;
@@ -212,21 +245,44 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
         // one per-lane element offset + wave-uniform (compile-time when FULL) tile offsets keep the 16*NT*NT
         // addresses out of VGPRs
         v4d acc[NT][NT];
+        if (PAIRED) {
+            // 16-byte accesses: see the index relabelling above (rows/cols of tile pairs interleaved by parity)
+            const unsigned lane_off2 = (unsigned)(2 * (l >> 4) * N + 2 * (l & 15));
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
+            for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < NT; ++tj)
+                for (int u = 0; u < NT / 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
-                    // identity padding beyond n: blockdiag(A, I)^-1 = blockdiag(A^-1, I)
-                    const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
-                    acc[ti][tj][r] = (FULL || (row < n && col < n)) ? A[uoff + lane_off] : ((row == col) ? 1.0 : 0.0);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned uoff = (unsigned)((32 * (ti >> 1) + 8 * r + (ti & 1)) * N + 32 * u);
+                        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(A + uoff + lane_off2));
+                        acc[ti][2 * u][r] = v[0];
+                        acc[ti][2 * u + 1][r] = v[1];
+                    }
+        } else {
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                        // identity padding beyond n: blockdiag(A, I)^-1 = blockdiag(A^-1, I)
+                        const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
+                        acc[ti][tj][r] = (FULL || (row < n && col < n)) ? A[uoff + lane_off] : ((row == col) ? 1.0 : 0.0);
+                    }
+        }
         unsigned long long bad = 0;  // wave-uniform: lanes that saw a multiplier above TAU (or NaN)
         double aop[NT], bop[NT];
 
+#ifdef TILE_DBG_REPEAT
+        for (int rep_ = 0; rep_ < TILE_DBG_REPEAT; ++rep_)
+#endif
+#ifdef TILE_DBG_NO_COMPUTE
+        if (false) {
+#else
         if (LOOKAHEAD) {
+#endif
             panel_to_lds<NT>(panel, acc, 0, q, c);
             __syncthreads();
             panel_solve<NT>(panel, 0, q, c, aop, bad);
@@ -250,7 +306,11 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
                             if (pend < NB) {
                                 const int tjx = pend / NT, ti = pend % NT;
                                 const int tj = tjx + (tjx >= tn ? 1 : 0);
+#ifndef TILE_DBG_NO_MFMA
                                 acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc[ti][tj], 0, 0, 0);
+#else
+                                acc[ti][tj][0] += aop[ti] * bop[tj];
+#endif
                                 ++pend;
                             }
                         }
@@ -269,7 +329,11 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
                     for (int s = 0; s < NS; ++s) {
                         // spread the remaining MFMAs evenly over the stages
                         issue_b(((NB - 2) * (s + 1)) / NS - ((NB - 2) * s) / NS);
+#ifndef TILE_DBG_NO_PANEL
                         ps.stage(s, panel, kb + 1, q, c, aop_next, bad);
+#else
+                        if (s >= 6) aop_next[s - 6] = aop[s - 6] * 0.5;
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     issue_b(NB);  // whatever is left (NT < 3)
@@ -284,8 +348,16 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
                 }
             }
         } else {
+#ifndef TILE_DBG_NO_COMPUTE
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
+#endif
+            for (int kb = 0; kb < (
+#ifdef TILE_DBG_NO_COMPUTE
+                0
+#else
+                NKB
+#endif
+                ); ++kb) {
                 panel_to_lds<NT>(panel, acc, kb, q, c);
                 __syncthreads();
                 panel_solve<NT>(panel, kb, q, c, aop, bad);
@@ -300,23 +372,260 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
             }
         }
 
+#ifdef TILE_DBG_REPEAT
+        bad = 0;
+#endif
         if (bad == 0) {
+            if (PAIRED) {
+                const unsigned lane_off2 = (unsigned)(2 * (l >> 4) * N + 2 * (l & 15));
 #pragma unroll
-            for (int ti = 0; ti < NT; ++ti)
+                for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < NT; ++tj)
+                    for (int u = 0; u < NT / 2; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
-                        const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
-                        if (FULL || (row < n && col < n)) X[uoff + lane_off] = acc[ti][tj][r];
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned uoff = (unsigned)((32 * (ti >> 1) + 8 * r + (ti & 1)) * N + 32 * u);
+                            v2d v;
+                            v[0] = acc[ti][2 * u][r];
+                            v[1] = acc[ti][2 * u + 1][r];
+                            __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(X + uoff + lane_off2));
+                        }
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                            const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
+                            if (FULL || (row < n && col < n)) X[uoff + lane_off] = acc[ti][tj][r];
+                        }
+            }
             if (info && l == 0) info[mat] = 0;
         } else if (l == 0) {
             const int slot = atomicAdd(work_count, 1);
             work_list[slot] = (int)mat;
         }
         if (LOOKAHEAD) __syncthreads();  // the next matrix's first panel write must not pass this one's last reads
+    }
+}
+
+// ================================================================================================================
+// SPD inputs: symmetric blocked sweep on LOWER-TRIANGULAR tile storage (the square-root-free member of the Cholesky
+// family: the same Schur complements as A = L L^T, pivots = squares of the Cholesky diagonal, no pivot search needed
+// and none wanted). Serves MATINV_ALGO_CHOLESKY for n <= 64 in place of the reference's four Cholesky kernel families
+// (/root/reference/src/inverse_cholesky_gpu.cu:55-765); the literal L L^T / L^-1 / L^-T L^-1 phases stay available in
+// the LDS family (and behind the reference's sub-phase entry points).
+//
+// Sweeping the pivot block K (D = W[K,K], P = W[:,K], Q = P D^-1) maps the symmetric W to the symmetric
+//     W[I,J] <- W[I,J] - Q[I] P[J]^T,    W[I,K] <- Q[I],    W[K,J] <- Q[J]^T,    W[K,K] <- -D^-1       (I, J not in K)
+// and after all blocks W = -A^-1. Only tiles (ti >= tj) are kept: NT(NT+1)/2 tiles = 80 VGPRs at n = 64 instead of 128
+// (3 waves per SIMD instead of 2), 10 MFMAs per block step instead of 16, and only the lower triangle is read from HBM.
+// Per tile it is the same single MFMA as the Gauss-Jordan kernel: A operand = -Q (rows K: +D^-1, C zeroed), B operand
+// = P^T -- by symmetry the OLD panel itself, read back from LDS in the layout it was staged in -- with -I_4 on the K
+// columns. Panel rows above the pivot block are not stored as a column: they are the pivot ROWS of tile row tK
+// (W[I,K] = W[K,I]^T), which already sit in A-operand lane order.
+// The upper triangle of the result is produced at the end by transposing each off-diagonal tile through LDS.
+// Rejected (some pivot <= 0: not SPD, or NaN): work list -> LDS Cholesky kernel, which also reports info exactly.
+template <int NT>
+__device__ __forceinline__ void spd_panel_to_lds(double *panel, const v4d (&acc)[NT][NT], int kb, int q, int c)
+{
+    const int tK = kb >> 2, rK = kb & 3, c0 = 4 * (kb & 3);
+    if (c >= c0 && c < c0 + 4) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            if (ti < tK) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) panel[(16 * ti + 4 * r + q) * 4 + (c - c0)] = acc[ti][tK][r];
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        if (ti >= tK) continue;
+        panel[(16 * ti + c) * 4 + q] = acc[tK][ti][rK];  // W[16ti + c][K0 + q] = W[K0 + q][16ti + c]
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void spd_prep_operands(v4d (&acc)[NT][NT], double (&bop)[NT], int kb, int q, int c)
+{
+    const int tK = kb >> 2, rK = kb & 3, c0 = 4 * (kb & 3);
+    const bool panel_lane = (c >= c0) && (c < c0 + 4);
+    const bool diag_lane = panel_lane && (c - c0 == q);
+    bop[tK] = panel_lane ? (diag_lane ? -1.0 : 0.0) : bop[tK];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        if (ti < tK) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ti][tK][r] = panel_lane ? 0.0 : acc[ti][tK][r];
+    }
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+        if (tj > tK) continue;
+        acc[tK][tj][rK] = 0.0;
+    }
+}
+
+template <int NT, bool FULL>
+__global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
+                                                                          int *info, int n_rt, unsigned batch,
+                                                                          int *work_count, int *work_list)
+{
+    constexpr int N = 16 * NT;
+    constexpr int NKB = 4 * NT;
+    constexpr int TSTRIDE = 17;  // padded row stride of the 16x16 transpose buffer (conflict-free ds_read_b64)
+    constexpr int LDS_DOUBLES = (N * 4 > 16 * TSTRIDE) ? N * 4 : 16 * TSTRIDE;
+    const int n = FULL ? N : n_rt;
+    __shared__ __attribute__((aligned(16))) double panel[LDS_DOUBLES];
+    const int l = threadIdx.x;
+
+    for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
+        const double *A = Ain.at(mat);
+        double *X = Xout.at(mat);
+        int q = l >> 4, c = l & 15;
+        const unsigned lane_off = (unsigned)((l >> 4) * n + (l & 15));
+        asm volatile("" : "+v"(q), "+v"(c));  // see matinv_gj_tile_f64
+
+        // W = A^T tile layout as in the Gauss-Jordan kernel; lower tiles only. In the diagonal tiles the strictly
+        // upper elements are fetched from their mirror position, so ONLY the lower triangle of A is ever read.
+        v4d acc[NT][NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) {
+                if (tj > ti) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                    double v;
+                    if (ti == tj) {
+                        const int hi = row > col ? row : col, lo = row > col ? col : row;
+                        // memory element (r_mem, c_mem) of column-major A sits at c_mem*n + r_mem; W[row][col] =
+                        // mem[row*n + col] = A[col][row]; its mirror mem[col*n + row]. Lower triangle of A
+                        // (r_mem >= c_mem) <=> mem index (small*n + big).
+                        v = (FULL || (row < n && col < n)) ? A[(unsigned)(lo * n + hi)] : ((row == col) ? 1.0 : 0.0);
+                    } else {
+                        // ti > tj: row > col: W[row][col] = mem[row*n + col] = A[col][row] is in A's UPPER triangle;
+                        // take its mirror A[row][col] = mem[col*n + row] instead
+                        v = (FULL || (row < n && col < n)) ? A[(unsigned)(col * n + row)] : 0.0;
+                    }
+                    acc[ti][tj][r] = v;
+                }
+            }
+        (void)lane_off;
+        unsigned long long bad = 0;
+        double aop[NT], bop[NT];
+
+        spd_panel_to_lds<NT>(panel, acc, 0, q, c);
+        __syncthreads();
+        {
+            PanelSolve<NT, true> ps0;
+#pragma unroll
+            for (int s = 0; s < PanelSolve<NT, true>::NSTAGE; ++s) ps0.stage(s, panel, 0, q, c, aop, bop, bad);
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int tK = kb >> 2;
+            spd_prep_operands<NT>(acc, bop, kb, q, c);
+            if (kb + 1 < NKB) {
+                const int tn = (kb + 1) >> 2;
+                // (a) the tiles the next panel is read from: column tn (ti >= tn) and row tn (tj < tn)
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    if (ti < tn) continue;
+                    acc[ti][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tn], acc[ti][tn], 0, 0, 0);
+                }
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+                    if (tj >= tn) continue;
+                    acc[tn][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tn], bop[tj], acc[tn][tj], 0, 0, 0);
+                }
+                // (b) the other lower tiles, pinned between the pieces of the next panel: 2 MFMAs cover the latency of
+                //     (a), then the panel is staged, then the remaining MFMAs are spread evenly over the solve stages.
+                //     Everything below is fully unrolled: the counters fold to literals.
+                constexpr int NB = NT * (NT + 1) / 2 - NT;
+                constexpr int NS = PanelSolve<NT, true>::NSTAGE;
+                double aop_next[NT], bop_next[NT];
+                PanelSolve<NT, true> ps;
+                int count = 0, ev = 0;  // MFMAs of (b) issued so far; next event (0 = stage the panel, 1 + s = stage s)
+                auto run_events = [&](bool flush) {
+#pragma unroll
+                    for (int e = 0; e < NS + 1; ++e) {
+                        const int lead = NB < 2 ? NB : 2;
+                        const int thr = (e == 0) ? lead : lead + ((NB - lead) * e) / NS;
+                        if (e == ev && (flush || thr <= count)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (e == 0) {
+                                __syncthreads();
+                                spd_panel_to_lds<NT>(panel, acc, kb + 1, q, c);
+                                __syncthreads();
+                            } else {
+                                ps.stage(e - 1, panel, kb + 1, q, c, aop_next, bop_next, bad);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            ++ev;
+                        }
+                    }
+                };
+                run_events(false);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) {
+                        if (tj > ti || ti == tn || tj == tn) continue;
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc[ti][tj], 0, 0, 0);
+                        ++count;
+                        run_events(false);
+                    }
+                run_events(true);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) { aop[ti] = aop_next[ti]; bop[ti] = bop_next[ti]; }
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) {
+                        if (tj > ti) continue;
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc[ti][tj], 0, 0, 0);
+                    }
+            }
+            (void)tK;
+        }
+
+        if (bad == 0) {
+            // W = -A^-1 (lower tiles). Lower tiles + diagonal tiles go out directly; the mirror of every off-diagonal
+            // tile is transposed through LDS so that it, too, is written as 128-byte row segments.
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+                    if (tj > ti) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                        if (FULL || (row < n && col < n)) X[(unsigned)(row * n + col)] = -acc[ti][tj][r];
+                    }
+                    if (tj < ti) {
+                        __syncthreads();
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) panel[(4 * r + q) * TSTRIDE + c] = -acc[ti][tj][r];
+                        __syncthreads();
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // element (row 16tj + 4r + q, col 16ti + c) of the result = tile(ti,tj)[c][4r + q]
+                            const int row = 16 * tj + 4 * r + q, col = 16 * ti + c;
+                            const double v = panel[c * TSTRIDE + 4 * r + q];
+                            if (FULL || (row < n && col < n)) X[(unsigned)(row * n + col)] = v;
+                        }
+                    }
+                }
+            if (info && l == 0) info[mat] = 0;
+        } else if (l == 0) {
+            const int slot = atomicAdd(work_count, 1);
+            work_list[slot] = (int)mat;
+        }
+        __syncthreads();
     }
 }
 
@@ -375,6 +684,64 @@ hipError_t launch_gj_tile<double>(int n, BatchRef<const double> A, BatchRef<doub
     if (e == hipSuccess) e = launch_gj_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
+}
+
+template <class T>
+bool spd_tile_supports(int n);
+template <>
+bool spd_tile_supports<double>(int n) { return n >= 1 && n <= 64; }
+template <>
+bool spd_tile_supports<float>(int) { return false; }
+
+template <class T>
+hipError_t launch_spd_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <>
+hipError_t launch_spd_tile<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t)
+{
+    return hipErrorInvalidValue;
+}
+template <>
+hipError_t launch_spd_tile<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
+                                   hipStream_t stream)
+{
+    if (!spd_tile_supports<double>(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int nt = (n + 15) / 16;
+    const unsigned grid = (unsigned)(batch < 256u * 12u * 4u ? batch : 256u * 12u * 4u);
+    const unsigned b = (unsigned)batch;
+#define SPD_LAUNCH(NT_)                                                                                               \
+    if (n == 16 * NT_)                                                                                                \
+        hipLaunchKernelGGL((matinv_spd_tile_f64<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((matinv_spd_tile_f64<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1)
+    switch (nt) {
+    case 1: SPD_LAUNCH(1); break;
+    case 2: SPD_LAUNCH(2); break;
+    case 3: SPD_LAUNCH(3); break;
+    default: SPD_LAUNCH(4); break;
+    }
+#undef SPD_LAUNCH
+    e = hipGetLastError();
+    if (e == hipSuccess) e = launch_chol_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream);
+    hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+
+const char *name_spd_tile(bool f64, int n)
+{
+    if (!f64) return "";
+    const bool full = (n % 16) == 0;
+    switch ((n + 15) / 16) {
+    case 1: return full ? "matinv_spd_tile_f64<1, true>" : "matinv_spd_tile_f64<1, false>";
+    case 2: return full ? "matinv_spd_tile_f64<2, true>" : "matinv_spd_tile_f64<2, false>";
+    case 3: return full ? "matinv_spd_tile_f64<3, true>" : "matinv_spd_tile_f64<3, false>";
+    default: return full ? "matinv_spd_tile_f64<4, true>" : "matinv_spd_tile_f64<4, false>";
+    }
 }
 
 const char *name_gj_tile(bool f64, int n)

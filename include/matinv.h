@@ -41,7 +41,9 @@ typedef enum {
                                      transform_matrix, src/gauss/batched_invert.cu:17-95, and the cuBLAS LU
                                      path src/gauss/inverse_gpu.cu:16-58                                   */
     MATINV_ALGO_CHOLESKY = 1      /* SPD matrices (only the lower triangle is read), full symmetric result.
-                                     Replaces the four Cholesky families of src/inverse_cholesky_gpu.cu     */
+                                     Replaces the four Cholesky families of src/inverse_cholesky_gpu.cu. LDS family:
+                                     literal L L^T, L^-1, L^-T L^-1; tile family: the square-root-free symmetric
+                                     blocked sweep (same Schur complements, pivots = squares of diag(L))       */
 } matinv_algo;
 
 /* Kernel families; MATINV_KERNEL_AUTO picks by (algo, dtype, n). The others force one family and
@@ -50,7 +52,8 @@ typedef enum {
     MATINV_KERNEL_AUTO = 0,
     MATINV_KERNEL_LDS = 1,     /* one workgroup per matrix, matrix resident in LDS, any n up to the LDS limit */
     MATINV_KERNEL_ROWLANE = 2, /* n <= 16: 64/npad matrices per wavefront, one row per lane, DPP broadcasts     */
-    MATINV_KERNEL_TILE = 3     /* 16 < n <= 64 (f64): one matrix per wavefront in 16x16 MFMA tiles             */
+    MATINV_KERNEL_TILE = 3     /* n <= 64 (f64): one matrix per wavefront in 16x16 fp64 MFMA tiles -- blocked Gauss-Jordan,
+                                  or for MATINV_ALGO_CHOLESKY the symmetric blocked sweep on lower-triangular tiles */
 } matinv_kernel;
 
 /* Invert `batch` matrices that are already resident in device memory.
