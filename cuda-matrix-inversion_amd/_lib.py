@@ -31,7 +31,8 @@ REFERENCE_DEVICE_NAMES = [
 ]
 NATIVE_NAMES = [
     "matinv_inverse_batched", "matinv_inverse_batched_ex", "matinv_select_kernel", "matinv_kernel_name",
-    "matinv_mean_batched", "matinv_variance_batched", "matinv_inverse_batched_host", "matinv_last_error",
+    "matinv_mean_batched", "matinv_variance_batched", "matinv_inverse_batched_host", "matinv_mean_batched_host",
+    "matinv_variance_batched_host", "matinv_last_error",
     "matinv_abi_version",
 ]
 
@@ -76,6 +77,9 @@ def lib() -> ctypes.CDLL:
         f.argtypes = [ci, ci, vp, vp, vp, vp, vp, sz, vp, vp]
     L.matinv_inverse_batched_host.restype = ci
     L.matinv_inverse_batched_host.argtypes = [ci, ci, ci, vp, vp, sz, vp]
+    for f in (L.matinv_mean_batched_host, L.matinv_variance_batched_host):
+        f.restype = ci
+        f.argtypes = [ci, ci, vp, vp, vp, vp, vp, sz, vp]
     L.matinv_last_error.restype = ctypes.c_char_p
     L.matinv_abi_version.restype = ci
     for suffix in ("", "_f32"):

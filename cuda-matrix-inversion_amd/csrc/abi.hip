@@ -265,6 +265,55 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
     return MATINV_OK;
 }
 
+// Host-pointer form of the fused pipeline (what gauss_bench's calcluateMean / calcluateVariance time,
+// /root/reference/src/gauss_bench.cu:127-265): allocate, H2D, one kernel, D2H of batch scalars, free.
+template <class T>
+int gp_host(int n, const void *hA, const void *hB, const void *hC, const void *hX, void *hOut, size_t batch, int *info,
+            bool variance)
+{
+    if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
+    if (batch == 0) return MATINV_OK;
+    if (!hA || !hB || !hC || !hX || !hOut) return fail(MATINV_ERR_ARG, "null host pointer");
+    int rc = check_device();
+    if (rc) return rc;
+    const size_t vec = (size_t)n * batch, mat = vec * n, xlen = variance ? batch : vec;
+    const bool log = detailed_logging();
+    const char *key = variance ? "calculate_variance_gpu" : "calculate_mean_gpu";
+    T *dA = nullptr, *dB = nullptr, *dC = nullptr, *dX = nullptr, *dOut = nullptr;
+    int *dInfo = nullptr;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](T **p, size_t count) {
+        if (e == hipSuccess) e = hipMalloc(p, count * sizeof(T));
+    };
+    alloc(&dA, vec), alloc(&dB, mat), alloc(&dC, vec), alloc(&dX, xlen), alloc(&dOut, batch);
+    if (e == hipSuccess && info) e = hipMalloc(&dInfo, batch * sizeof(int));
+    const double t0 = now_ms();
+    auto h2d = [&](T *d, const void *h, size_t count) {
+        if (e == hipSuccess) e = hipMemcpy(d, h, count * sizeof(T), hipMemcpyHostToDevice);
+    };
+    h2d(dA, hA, vec), h2d(dB, hB, mat), h2d(dC, hC, vec), h2d(dX, hX, xlen);
+    const double t1 = now_ms();
+    if (e == hipSuccess) {
+        rc = gp_dispatch<T>(n, dA, dB, dC, variance ? nullptr : dX, variance ? dX : nullptr, dOut, batch, dInfo, nullptr,
+                            variance);
+        if (rc == MATINV_OK && log) e = hipDeviceSynchronize();
+    }
+    const double t2 = now_ms();
+    if (e == hipSuccess && rc == MATINV_OK) e = hipMemcpy(hOut, dOut, batch * sizeof(T), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rc == MATINV_OK && info) e = hipMemcpy(info, dInfo, batch * sizeof(int), hipMemcpyDeviceToHost);
+    const double t3 = now_ms();
+    (void)hipFree(dA), (void)hipFree(dB), (void)hipFree(dC), (void)hipFree(dX), (void)hipFree(dOut);
+    if (dInfo) (void)hipFree(dInfo);
+    if (rc != MATINV_OK) return rc;
+    if (e != hipSuccess) return fail_hip(e, "pipeline host<->device");
+    if (log) {
+        timer_log(key, "htod", batch, n, t1 - t0);
+        timer_log(key, "ker", batch, n, t2 - t1);
+        timer_log(key, "dtoh", batch, n, t3 - t2);
+    }
+    return MATINV_OK;
+}
+
 // Reference error contract: message on stderr, then exit (include/helper_gpu.h:9-18, helper_cpu.h:12-21 there).
 void die_on(int rc, const char *fn)
 {
@@ -333,6 +382,22 @@ int matinv_variance_batched(int dtype, int n, const void *dAs, const void *dBs, 
 {
     if (dtype == MATINV_F64) return gp_dispatch<double>(n, dAs, dBs, dCs, nullptr, dEs, dVars, batch, dInfo, stream, true);
     if (dtype == MATINV_F32) return gp_dispatch<float>(n, dAs, dBs, dCs, nullptr, dEs, dVars, batch, dInfo, stream, true);
+    return fail(MATINV_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int matinv_mean_batched_host(int dtype, int n, const void *hAs, const void *hBs, const void *hCs, const void *hDs,
+                             void *hMeans, size_t batch, int *info)
+{
+    if (dtype == MATINV_F64) return gp_host<double>(n, hAs, hBs, hCs, hDs, hMeans, batch, info, false);
+    if (dtype == MATINV_F32) return gp_host<float>(n, hAs, hBs, hCs, hDs, hMeans, batch, info, false);
+    return fail(MATINV_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int matinv_variance_batched_host(int dtype, int n, const void *hAs, const void *hBs, const void *hCs, const void *hEs,
+                                 void *hVars, size_t batch, int *info)
+{
+    if (dtype == MATINV_F64) return gp_host<double>(n, hAs, hBs, hCs, hEs, hVars, batch, info, true);
+    if (dtype == MATINV_F32) return gp_host<float>(n, hAs, hBs, hCs, hEs, hVars, batch, info, true);
     return fail(MATINV_ERR_ARG, "unknown dtype %d", dtype);
 }
 

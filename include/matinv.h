@@ -94,6 +94,13 @@ int matinv_variance_batched(int dtype, int n, const void *dAs, const void *dBs, 
  * `info` is an optional host int[batch]. Synchronous. */
 int matinv_inverse_batched_host(int algo, int dtype, int n, const void *hA, void *hAinv, size_t batch, int *info);
 
+/* Host-pointer form of the fused pipeline (what gauss_bench times): H2D, one kernel, D2H of `batch` scalars.
+ * Inputs are NOT modified (the reference CPU path destroys Bs and Cs, include/gauss_cpu.h:42 there). Synchronous. */
+int matinv_mean_batched_host(int dtype, int n, const void *hAs, const void *hBs, const void *hCs, const void *hDs,
+                             void *hMeans, size_t batch, int *info);
+int matinv_variance_batched_host(int dtype, int n, const void *hAs, const void *hBs, const void *hCs, const void *hEs,
+                                 void *hVars, size_t batch, int *info);
+
 const char *matinv_last_error(void);
 int matinv_abi_version(void);
 

@@ -1,0 +1,63 @@
+"""The reference's two command lines, end to end on an MI355X: same argv, same output columns, errors at the
+fixtures' rounding floor (SURVEY.md 8b 'CLI contract')."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import REFDATA, ROOT
+
+pytestmark = pytest.mark.gpu
+HOST = os.path.join(ROOT, "cuda-matrix-inversion_amd", "host")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "cuda-matrix-inversion_amd"), "-s", "-j4"], check=True)
+    subprocess.run(["make", "-C", HOST, "-s"], check=True)
+    subprocess.run(["make", "-C", HOST, "-s", "DTYPE=float"], check=True)
+
+
+def run(exe, *args, env=None):
+    e = dict(os.environ, OMP_NUM_THREADS="8")
+    e.update(env or {})
+    p = subprocess.run([os.path.join(HOST, exe), *args], capture_output=True, text=True, env=e, timeout=300)
+    assert p.returncode == 0, p.stderr
+    return p.stdout.strip().splitlines()
+
+
+@pytest.mark.parametrize("exe,tol", [("inverse_bench", 5e-4), ("inverse_bench_f32", 6e-4)])
+@pytest.mark.parametrize("d,n", [("inverse_100_8x8", 8), ("inverse_100_16x16", 16), ("inverse_32_32x32", 32)])
+def test_inverse_bench(exe, tol, d, n):
+    lines = run(exe, os.path.join(REFDATA, d), "3", "4", "-csv")
+    names = [ln.split()[3] for ln in lines]
+    assert names == ["lu_blas_cpu", "lu_blas_omp_cpu", "chol_gpu", "chol_mm2_gpu", "gauss_batched_gpu", "lu_cuda_batched_gpu"]
+    for ln in lines:
+        f = ln.split()
+        assert int(f[1]) == n and int(f[2]) == 3 and len(f) == 8
+        assert float(f[4]) > 0
+        assert float(f[7]) < tol, ln  # sum|inv - aInv.mats| per matrix: the 4-digit rounding floor (3.4e-4 at 8x8)
+
+
+@pytest.mark.parametrize("exe", ["gauss_bench", "gauss_bench_f32"])
+@pytest.mark.parametrize("d", ["gaussian_100_8x8", "gaussian_100_16x16", "gaussian_32_32x32", "gaussian_12_64x64"])
+def test_gauss_bench(exe, d):
+    lines = run(exe, os.path.join(REFDATA, d), "2", "3", "-csv")
+    names = [ln.split()[3] for ln in lines]
+    assert names == ["means_cpu", "variances_cpu", "means_gpu", "variances_gpu"]
+    for ln in lines:
+        assert float(ln.split()[7]) < 6e-5, ln
+
+
+def test_detailed_logging_lines():
+    """log=1 build of the reference: name,batch,n,ms,ns CRLF lines with the reference's key names (timer.h:8-9)."""
+    p = subprocess.run([os.path.join(HOST, "inverse_bench"), os.path.join(REFDATA, "inverse_100_8x8"), "1", "1"],
+                       capture_output=True, text=True, env=dict(os.environ, MATINV_DETAILED_LOGGING="1"))
+    assert p.returncode == 0, p.stderr
+    keys = [ln.split(",")[0] for ln in p.stdout.splitlines() if "," in ln]
+    for k in ("lu_blas_cpu", "lu_blas_omp_cpu", "decompose_cholesky_batched_gpu_mem_htod", "decompose_cholesky_batched_gpu_ker",
+              "cholesky_mm2_batched_gpu_ker", "inverse_gauss_batched_gpu_mem_htod", "inverse_gauss_batched_gpu_ker",
+              "inverse_gauss_batched_gpu_mem_dtoh", "inverse_lu_cuda_batched_gpu_ker", "gauss_batched_gpu"):
+        assert k in keys, (k, keys)
+    f = [ln for ln in p.stdout.splitlines() if ln.startswith("inverse_gauss_batched_gpu_ker,")][0].strip().split(",")
+    assert f[1] == "100" and f[2] == "8" and float(f[3]) >= 0 and int(f[4]) >= 0
