@@ -1,0 +1,165 @@
+// tile4_kernels.hip -- kernel family "TILE" for 64 < n <= 128 (f64): FOUR wavefronts per matrix.
+//
+// Same blocked Gauss-Jordan on 16x16 fp64 MFMA accumulator tiles as tile_kernels.hip (read that header first), but a
+// 128 x 128 matrix is 64 tiles = 512 VGPRs per lane -- more than one wavefront may hold. A 256-thread workgroup owns a
+// matrix; wavefront w holds the tile COLUMNS w, w+4 (all NT tile rows of them, <= 16 tiles = 128 VGPRs). That split
+// keeps the two operands of the rank-4 update cheap:
+//   * B operand = pivot rows of the wave's own columns = its own accumulator registers, no exchange at all;
+//   * A operand = -W[:,K] D^-1 is needed by every wave: the wave that owns tile column kb/4 stages the 4 pivot columns
+//     in LDS (4 KB), then all four waves solve the 4x4 pivot block redundantly and form the same Aop (no second
+//     exchange, and the acceptance flag comes out identical in every wave).
+// Two workgroup barriers per block step (panel visible / panel consumed). Rejected matrices (a multiplier above TAU)
+// go to the same device work list and are redone by the pivoted LDS kernel, which handles n <= 141.
+//
+// Replaces, for 64 < n <= 128, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95.
+#include "tile_common.hpp"
+
+namespace matinv {
+
+constexpr int T4_WAVES = 4;
+
+// NT = tiles per dimension (5..8), NC = tile columns per wave = ceil(NT / 4)
+template <int NT, bool FULL>
+__global__ __launch_bounds__(64 * T4_WAVES, FULL ? 2 : 1) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
+                                                                       int *info, int n_rt, unsigned batch,
+                                                                       int *work_count, int *work_list)
+{
+    constexpr int N = 16 * NT;
+    constexpr int NKB = 4 * NT;
+    constexpr int NC = (NT + T4_WAVES - 1) / T4_WAVES;
+    const int n = FULL ? N : n_rt;
+    __shared__ __attribute__((aligned(16))) double panel[N * 4];  // [row][4 pivot columns]
+    const int l = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;  // wave-uniform
+
+    for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
+        const double *A = Ain.at(mat);
+        double *X = Xout.at(mat);
+        int q = l >> 4, c = l & 15;
+        const unsigned lane_off = (unsigned)((l >> 4) * n + (l & 15));
+        asm volatile("" : "+v"(q), "+v"(c));  // keep LICM from hoisting ~100 per-lane constants (see tile_kernels.hip)
+
+        // acc[ti][jl] = tile (ti, w + 4*jl); W = A^T as in the single-wave kernel
+        v4d acc[NT][NC];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int jl = 0; jl < NC; ++jl) {
+                const int tj = w + T4_WAVES * jl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                    const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
+                    const bool in = (tj < NT) && (FULL || (row < n && col < n));
+                    acc[ti][jl][r] = in ? A[uoff + lane_off] : ((row == col) ? 1.0 : 0.0);
+                }
+            }
+        unsigned long long bad = 0;
+
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int tK = kb >> 2, rK = kb & 3, c0 = 4 * (kb & 3);
+            const int owner = tK % T4_WAVES, jo = tK / T4_WAVES;  // wave and local column holding the pivot columns
+            const bool panel_lane = (c >= c0) && (c < c0 + 4);
+            const bool diag_lane = panel_lane && (c - c0 == q);
+            // 1. the owner stages the 4 pivot columns, [row][4]
+            if (w == owner && panel_lane) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) panel[(16 * ti + 4 * r + q) * 4 + (c - c0)] = acc[ti][jo][r];
+            }
+            __syncthreads();
+            // 2.-4. every wave: D^-1 (column q) and the A operand of all NT tile rows
+            double aop[NT];
+            panel_solve<NT>(panel, kb, q, c, aop, bad);
+            __syncthreads();  // panel consumed: the next owner may overwrite it
+            // 5. B operand: pivot rows of the wave's own columns; I_4 on the pivot columns (owner only)
+            double bop[NC];
+#pragma unroll
+            for (int jl = 0; jl < NC; ++jl) bop[jl] = acc[tK][jl][rK];
+            if (w == owner) bop[jo] = panel_lane ? (diag_lane ? 1.0 : 0.0) : bop[jo];
+            // 6. C operand: zero on the pivot columns (owner) and on the pivot rows (everyone)
+            if (w == owner) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[ti][jo][r] = panel_lane ? 0.0 : acc[ti][jo][r];
+            }
+#pragma unroll
+            for (int jl = 0; jl < NC; ++jl) acc[tK][jl][rK] = 0.0;
+            // 7. rank-4 update of the wave's tiles
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int jl = 0; jl < NC; ++jl)
+                    acc[ti][jl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[jl], acc[ti][jl], 0, 0, 0);
+        }
+
+        if (bad == 0) {  // identical in all four waves (they evaluate the same D and the same Aop)
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int jl = 0; jl < NC; ++jl) {
+                    const int tj = w + T4_WAVES * jl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                        const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
+                        if ((tj < NT) && (FULL || (row < n && col < n))) X[uoff + lane_off] = acc[ti][jl][r];
+                    }
+                }
+            if (info && threadIdx.x == 0) info[mat] = 0;
+        } else if (threadIdx.x == 0) {
+            const int slot = atomicAdd(work_count, 1);
+            work_list[slot] = (int)mat;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+bool tile4_supports_f64(int n) { return n > 64 && n <= 128; }
+
+hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
+                               hipStream_t stream)
+{
+    if (!tile4_supports_f64(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int nt = (n + 15) / 16;
+    const unsigned grid = (unsigned)(batch < 256u * 2u * 4u ? batch : 256u * 2u * 4u);
+    const unsigned b = (unsigned)batch;
+#define T4_LAUNCH(NT_)                                                                                                \
+    if (n == 16 * NT_)                                                                                                \
+        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true>), dim3(grid), dim3(64 * T4_WAVES), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false>), dim3(grid), dim3(64 * T4_WAVES), 0, stream, A, X, info, n, b, ws, ws + 1)
+    switch (nt) {
+    case 5: T4_LAUNCH(5); break;
+    case 6: T4_LAUNCH(6); break;
+    case 7: T4_LAUNCH(7); break;
+    default: T4_LAUNCH(8); break;
+    }
+#undef T4_LAUNCH
+    e = hipGetLastError();
+    if (e == hipSuccess) e = launch_gj_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream);
+    hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+
+const char *name_gj_tile4_f64(int n)
+{
+    const bool full = (n % 16) == 0;
+    switch ((n + 15) / 16) {
+    case 5: return full ? "matinv_gj_tile4_f64<5, true>" : "matinv_gj_tile4_f64<5, false>";
+    case 6: return full ? "matinv_gj_tile4_f64<6, true>" : "matinv_gj_tile4_f64<6, false>";
+    case 7: return full ? "matinv_gj_tile4_f64<7, true>" : "matinv_gj_tile4_f64<7, false>";
+    default: return full ? "matinv_gj_tile4_f64<8, true>" : "matinv_gj_tile4_f64<8, false>";
+    }
+}
+
+}  // namespace matinv

@@ -33,37 +33,9 @@
 // Replaces the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95.
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "tile_common.hpp"
 
 namespace matinv {
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-constexpr double TILE_TAU = 4.0;
-
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    // v_rcp_f64 + two Newton steps: full fp64 accuracy for normal x (no denormal/overflow fix-up needed here:
-    // a pivot that small or large fails the TAU acceptance test and the matrix goes to the pivoted fallback)
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return r;
-}
-
-// Acceptance test, wave-wide, evaluated on the spot and accumulated in an SGPR pair: bad |= ballot(!(|v| <= TAU)) (NaN
-// fails). It is inline asm on purpose: written in C++ (`ok = ok && ...`, `bad |= __ballot(...)`, or a lane-local running
-// max) hipcc sinks every comparison to the end of the kernel and keeps all multipliers of all 4*NT block steps alive
-// (hundreds of VGPRs, or dozens of SGPR pairs spilled through v_writelane -- measured: 2x slower). TAU = 4.0 is an
-// inline constant of the ISA.
-__device__ __forceinline__ void note_fail(unsigned long long &bad, double v)
-{
-    static_assert(TILE_TAU == 4.0, "the asm below hard-codes the inline constant 4.0");
-    asm volatile("v_cmp_nle_f64_e64 vcc, |%1|, 4.0\n\ts_or_b64 %0, %0, vcc" : "+s"(bad) : "v"(v) : "vcc");
-}
 
 // ---- pieces of one block step ---------------------------------------------------------------------------------
 
@@ -78,116 +50,6 @@ __device__ __forceinline__ void panel_to_lds(double *panel, const v4d (&acc)[NT]
 #pragma unroll
             for (int r = 0; r < 4; ++r) panel[(16 * ti + 4 * r + q) * 4 + (c - c0)] = acc[ti][tK][r];
     }
-}
-
-// 2.-4. read the pivot block D and this lane's panel rows from LDS, invert D (column q), form the A operand
-//       aop[ti] = Aop[16ti + c][q] and update the acceptance flag. Split into NSTAGE pieces of roughly equal
-//       VALU/LDS work so the look-ahead loop can issue one MFMA of the CURRENT block step between two pieces of the
-//       NEXT step's panel (hardware issues in order: MFMA, ~64 cycles of VALU, MFMA, ... keeps both pipes busy).
-// !(v > 0) accumulated like note_fail: SPD mode rejects a non-positive (or NaN) pivot
-__device__ __forceinline__ void note_nonpositive(unsigned long long &bad, double v)
-{
-    asm volatile("v_cmp_ngt_f64_e64 vcc, %1, 0\n\ts_or_b64 %0, %0, vcc" : "+s"(bad) : "v"(v) : "vcc");
-}
-
-// SPD = true: symmetric blocked sweep for SPD input (see matinv_spd_tile_f64). Same arithmetic for D^-1 and Aop; the
-// acceptance test becomes "all four pivots of D positive" (they are the squares of the Cholesky diagonal), and the
-// stage of tile row ti also returns bsym[ti] = P[16ti + c][q], the B operand by symmetry (W[K, J] = W[J, K]^T).
-template <int NT, bool SPD = false>
-struct PanelSolve {
-    static constexpr int NSTAGE = 6 + NT;
-    double d[4][4];
-    double r0, r1, r2, r3, l10, l20, l30, l21, l31, l32, u11, u12, u13, u22, u23, u33;
-    double a21, a22, a23, a31, a32, a33, b32, b33, y0, y1, y2, y3, x0, x1, x2, x3;
-
-    __device__ __forceinline__ void stage(int s, const double *panel, int kb, int q, int c, double (&aop)[NT],
-                                          unsigned long long &bad)
-    {
-        double unused[NT];
-        stage(s, panel, kb, q, c, aop, unused, bad);
-    }
-    __device__ __forceinline__ void stage(int s, const double *panel, int kb, int q, int c, double (&aop)[NT],
-                                          double (&bsym)[NT], unsigned long long &bad)
-    {
-        const int tK = kb >> 2, c0 = 4 * (kb & 3), K0 = 4 * kb;
-        const bool panel_lane = (c >= c0) && (c < c0 + 4);
-        if (s == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = panel[(K0 + i) * 4 + j];
-            // LU of D without pivoting (multipliers checked below)
-            r0 = fast_rcp(d[0][0]);
-            l10 = d[1][0] * r0, l20 = d[2][0] * r0, l30 = d[3][0] * r0;
-        } else if (s == 1) {
-            u11 = __builtin_fma(-l10, d[0][1], d[1][1]), u12 = __builtin_fma(-l10, d[0][2], d[1][2]);
-            u13 = __builtin_fma(-l10, d[0][3], d[1][3]);
-            a21 = __builtin_fma(-l20, d[0][1], d[2][1]), a22 = __builtin_fma(-l20, d[0][2], d[2][2]);
-            a23 = __builtin_fma(-l20, d[0][3], d[2][3]);
-            a31 = __builtin_fma(-l30, d[0][1], d[3][1]), a32 = __builtin_fma(-l30, d[0][2], d[3][2]);
-            a33 = __builtin_fma(-l30, d[0][3], d[3][3]);
-            r1 = fast_rcp(u11);
-        } else if (s == 2) {
-            l21 = a21 * r1, l31 = a31 * r1;
-            u22 = __builtin_fma(-l21, u12, a22), u23 = __builtin_fma(-l21, u13, a23);
-            b32 = __builtin_fma(-l31, u12, a32), b33 = __builtin_fma(-l31, u13, a33);
-            r2 = fast_rcp(u22);
-            l32 = b32 * r2;
-            u33 = __builtin_fma(-l32, u23, b33);
-        } else if (s == 3) {
-            r3 = fast_rcp(u33);
-            if (SPD) {
-                note_nonpositive(bad, d[0][0]), note_nonpositive(bad, u11);
-                note_nonpositive(bad, u22), note_nonpositive(bad, u33);
-            } else {
-                note_fail(bad, l10), note_fail(bad, l20), note_fail(bad, l30);
-                note_fail(bad, l21), note_fail(bad, l31), note_fail(bad, l32);
-            }
-            // a zero / non-finite last pivot needs no test of its own: r3 = inf/NaN makes x, hence every Aop entry
-            // outside the pivot rows (0 * inf = NaN included), fail the test in the last stages
-        } else if (s == 4) {
-            // L y = e_q
-            y0 = (q == 0) ? 1.0 : 0.0;
-            y1 = __builtin_fma(-l10, y0, (q == 1) ? 1.0 : 0.0);
-            y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, y0, (q == 2) ? 1.0 : 0.0));
-            y3 = __builtin_fma(-l32, y2, __builtin_fma(-l31, y1, __builtin_fma(-l30, y0, (q == 3) ? 1.0 : 0.0)));
-        } else if (s == 5) {
-            // U x = y : x = column q of D^-1
-            x3 = y3 * r3;
-            x2 = __builtin_fma(-u23, x3, y2) * r2;
-            x1 = __builtin_fma(-u13, x3, __builtin_fma(-u12, x2, y1)) * r1;
-            x0 = __builtin_fma(-d[0][3], x3, __builtin_fma(-d[0][2], x2, __builtin_fma(-d[0][1], x1, y0))) * r0;
-        } else {
-            const int ti = s - 6;
-            const double *w = &panel[(16 * ti + c) * 4];
-            const double w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-            double v = -__builtin_fma(w3, x3, __builtin_fma(w2, x2, __builtin_fma(w1, x1, w0 * x0)));
-            if (ti == tK) {
-                // pivot rows: D^-1 itself (their C operand is zeroed), exempt from the multiplier test
-                const int m = c - c0;
-                const double x01 = (m & 1) ? x1 : x0, x23 = (m & 1) ? x3 : x2;
-                const double xm = (m & 2) ? x23 : x01;
-                if (!SPD) note_fail(bad, panel_lane ? 0.0 : v);
-                v = panel_lane ? xm : v;
-            } else {
-                if (!SPD) note_fail(bad, v);
-            }
-            aop[ti] = v;
-            if (SPD) {
-                const double w01 = (q & 1) ? w1 : w0, w23 = (q & 1) ? w3 : w2;
-                bsym[ti] = (q & 2) ? w23 : w01;
-            }
-        }
-    }
-};
-
-template <int NT>
-__device__ __forceinline__ void panel_solve(const double *panel, int kb, int q, int c, double (&aop)[NT],
-                                            unsigned long long &bad)
-{
-    PanelSolve<NT> ps;
-#pragma unroll
-    for (int s = 0; s < PanelSolve<NT>::NSTAGE; ++s) ps.stage(s, panel, kb, q, c, aop, bad);
 }
 
 // 5.+6. B operand (pivot rows as they stand, I_4 on the pivot columns) and C operand (zero on the pivot columns: the
@@ -633,7 +495,7 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
 template <class T>
 bool tile_family_supports(int n);
 template <>
-bool tile_family_supports<double>(int n) { return n >= 1 && n <= 64; }
+bool tile_family_supports<double>(int n) { return n >= 1 && n <= 128; }
 template <>
 bool tile_family_supports<float>(int) { return false; }
 
@@ -652,6 +514,7 @@ hipError_t launch_gj_tile<double>(int n, BatchRef<const double> A, BatchRef<doub
 {
     if (!tile_family_supports<double>(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
+    if (n > 64) return launch_gj_tile4_f64(n, A, X, batch, info, stream);
     // work list for matrices that fail the acceptance test: [0] = count, [1..batch] = indices (stream-ordered pool)
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -747,6 +610,7 @@ const char *name_spd_tile(bool f64, int n)
 const char *name_gj_tile(bool f64, int n)
 {
     if (!f64) return "";
+    if (n > 64) return name_gj_tile4_f64(n);
     const bool full = (n % 16) == 0;
     switch ((n + 15) / 16) {
     case 1: return full ? "matinv_gj_tile_f64<1, true, true>" : "matinv_gj_tile_f64<1, false, false>";
