@@ -285,17 +285,13 @@ __global__ __launch_bounds__(LDS_THREADS) void matinv_chol_lds_worklist(BatchRef
 // With M = L L^T:  u^T M^-1 w = (L^-1 u) . (L^-1 w): one factorisation and two forward substitutions;
 // the inverse is never formed.
 template <class T>
-__global__ __launch_bounds__(LDS_THREADS) void matinv_gp_lds(const T *As, const T *Bs, const T *Cs, const T *Ds,
-                                                             const T *Es, T *out, int *info, int n)
+__device__ __forceinline__ void gp_lds_one(const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out,
+                                           int *info, int n, size_t k_mat, unsigned char *smem_raw, T *s_part)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ld = lds_ld(n);
     T *a = reinterpret_cast<T *>(smem_raw);
     T *u = a + (size_t)n * ld;
     T *w = u + n;
-    __shared__ T s_part[LDS_THREADS / 64];
-
-    const size_t k_mat = blockIdx.x;
     const T *B = Bs + k_mat * (size_t)n * n;
     const int t = threadIdx.x;
     const int tx = t & 63, ty = t >> 6;
@@ -341,6 +337,30 @@ __global__ __launch_bounds__(LDS_THREADS) void matinv_gp_lds(const T *As, const 
         for (int i = 0; i < LDS_THREADS / 64; ++i) q += s_part[i];
         out[k_mat] = variance ? Es[k_mat] - q : q;
         if (info) info[k_mat] = 0;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(LDS_THREADS) void matinv_gp_lds(const T *As, const T *Bs, const T *Cs, const T *Ds,
+                                                             const T *Es, T *out, int *info, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ T s_part[LDS_THREADS / 64];
+    gp_lds_one<T>(As, Bs, Cs, Ds, Es, out, info, n, blockIdx.x, smem_raw, s_part);
+}
+
+// the same over a device-side work list (fallback of matinv_gp_tile_f64)
+template <class T>
+__global__ __launch_bounds__(LDS_THREADS) void matinv_gp_lds_worklist(const T *As, const T *Bs, const T *Cs, const T *Ds,
+                                                                      const T *Es, T *out, int *info, int n,
+                                                                      const int *work_count, const int *work_list)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ T s_part[LDS_THREADS / 64];
+    const int count = *work_count;
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        gp_lds_one<T>(As, Bs, Cs, Ds, Es, out, info, n, (size_t)work_list[i], smem_raw, s_part);
+        __syncthreads();
     }
 }
 
@@ -415,6 +435,18 @@ hipError_t launch_gp_lds(int n, const T *As, const T *Bs, const T *Cs, const T *
                        out, info, n);
     return hipGetLastError();
 }
+template <class T>
+hipError_t launch_gp_lds_worklist(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out,
+                                  const int *work_count, const int *work_list, int *info, hipStream_t stream)
+{
+    if (!lds_family_supports<T>(n)) return hipErrorInvalidValue;
+    const size_t bytes = lds_bytes<T>(n);
+    hipError_t e = prepare_lds(matinv_gp_lds_worklist<T>, bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(matinv_gp_lds_worklist<T>, dim3(1024), dim3(LDS_THREADS), bytes, stream, As, Bs, Cs, Ds, Es, out,
+                       info, n, work_count, work_list);
+    return hipGetLastError();
+}
 #define INST(T)                                                                                                        \
     template hipError_t launch_gj_lds<T>(int, BatchRef<const T>, BatchRef<T>, size_t, int *, hipStream_t);            \
     template hipError_t launch_gj_lds_worklist<T>(int, BatchRef<const T>, BatchRef<T>, const int *, const int *,      \
@@ -423,7 +455,9 @@ hipError_t launch_gp_lds(int n, const T *As, const T *Bs, const T *Cs, const T *
     template hipError_t launch_chol_lds_worklist<T>(int, BatchRef<const T>, BatchRef<T>, const int *, const int *,    \
                                                     int *, hipStream_t);                                              \
     template hipError_t launch_gp_lds<T>(int, const T *, const T *, const T *, const T *, const T *, T *, size_t,     \
-                                         int *, hipStream_t);
+                                         int *, hipStream_t);                                                         \
+    template hipError_t launch_gp_lds_worklist<T>(int, const T *, const T *, const T *, const T *, const T *, T *,    \
+                                                  const int *, const int *, int *, hipStream_t);
 INST(double)
 INST(float)
 #undef INST

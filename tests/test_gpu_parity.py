@@ -326,6 +326,50 @@ def test_pipeline_synthetic(n, dtype):
     assert np.abs(m - wm).max() < tol and np.abs(v - wv).max() < tol
 
 
+def test_pipeline_not_spd_reports_info_and_nan():
+    n, batch = 32, 6
+    rng = np.random.default_rng(5)
+    B = spd_batch(n, batch, seed=5).reshape(batch, n, n)
+    B[3, 7, 7] = -50.0                       # breaks positive definiteness of item 3
+    a, c, d_ = (rng.random(batch * n) for _ in range(3))
+    t = [dev(x) for x in (a, B.reshape(-1), c, d_)]
+    info = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
+    m = api.calcluateMean(n, t[0], t[1], t[2], t[3], info=info).cpu().numpy()
+    inf = info.cpu().numpy()
+    assert inf[3] == 8 and (np.delete(inf, 3) == 0).all()
+    assert np.isnan(m[3])
+    want = oracle.mean_batched(np.delete(a.reshape(batch, n), 3, 0).reshape(-1), np.delete(B, 3, 0).reshape(-1),
+                               np.delete(c.reshape(batch, n), 3, 0).reshape(-1),
+                               np.delete(d_.reshape(batch, n), 3, 0).reshape(-1), n)
+    assert np.abs(np.delete(m, 3) - want).max() < 1e-10
+
+
+@pytest.mark.parametrize("n,batch", [(16, 200_000), (64, 100_000)])
+def test_pipeline_full_size_properties(n, batch):
+    """Size-independent checks at BASELINE batch sizes: mean is bilinear in (a, d); var(a) = e - mean(a, a);
+    scaling B and c by 4 divides the quadratic form by 4 exactly."""
+    g = torch.Generator(device="cuda").manual_seed(99 + n)
+    r = torch.rand((batch, n, n), generator=g, dtype=torch.float64, device="cuda")
+    B = (r + r.transpose(1, 2) + n * torch.eye(n, dtype=torch.float64, device="cuda")).reshape(-1)
+    del r
+    a, c, d_ = (torch.rand(batch * n, generator=g, dtype=torch.float64, device="cuda") for _ in range(3))
+    e = torch.rand(batch, generator=g, dtype=torch.float64, device="cuda")
+    m_ad = api.calcluateMean(n, a, B, c, d_)
+    m_da = api.calcluateMean(n, d_, B, c, a)
+    assert float((m_ad - m_da).abs().max()) < 1e-13                       # symmetry of M^-1
+    m_aa = api.calcluateMean(n, a, B, c, a)
+    v = api.calcluateVariance(n, a, B, c, e)
+    assert float((v - (e - m_aa)).abs().max()) < 1e-13
+    m_2 = api.calcluateMean(n, a, B, c, d_ * 2.0)
+    assert torch.equal(m_2, m_ad * 2.0)                                    # linear in d, exact for powers of two
+    m_s = api.calcluateMean(n, a, B * 4.0, c * 4.0, d_)
+    assert torch.equal(m_s * 4.0, m_ad)
+    idx = torch.arange(0, batch, batch // 50, device="cuda")[:50].cpu().numpy()
+    sel = lambda t, w: t.view(batch, w)[idx].reshape(-1).cpu().numpy()
+    want = oracle.mean_batched(sel(a, n), sel(B, n * n), sel(c, n), sel(d_, n), n)
+    assert np.abs(m_ad[idx].cpu().numpy() - want).max() < 1e-10
+
+
 # ------------------------------------------------------------- full-size, size-independent properties
 @pytest.mark.parametrize("n,batch", [(16, 100_000), (64, 100_000)])
 @pytest.mark.parametrize("algo", [GJ, CH])
