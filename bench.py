@@ -79,14 +79,18 @@ def cpu_baseline(n, algo_name, target_seconds=12.0):
     oracle.inverse_batched(probe, n, algo, threads=cores)
     dt = max(time.perf_counter() - t0, 1e-6)
     rate = (probe.size // (n * n)) / dt
-    k = int(min(max(rate * target_seconds, 1024), 2_000_000, 2e9 / (n * n * 8)))
+    # a sample of at most ~1 GB, inverted `passes` times back to back so that the timed CPU work is ~target_seconds
+    k = int(min(max(rate * target_seconds, 1024), 1e9 / (n * n * 8)))
+    passes = max(1, int(round(rate * target_seconds / k)))
     a = sample(k)
     t0 = time.perf_counter()
-    oracle.inverse_batched(a, n, algo, threads=cores)
+    for _ in range(passes):
+        oracle.inverse_batched(a, n, algo, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": k / dt, "unit": "inversions/s", "cores": cores, "kind": "port",
-            "sample": f"{k} SPD {n}x{n} fp64 matrices, oracle {'Gauss-Jordan partial pivot' if algo_name == 'gj' else 'Cholesky'}"
-                      f" (C, OpenMP {cores} threads), {dt:.1f} s"}
+    return {"value": k * passes / dt, "unit": "inversions/s", "cores": cores, "kind": "port",
+            "sample": f"{k} SPD {n}x{n} fp64 matrices x {passes} passes, oracle "
+                      f"{'Gauss-Jordan partial pivot' if algo_name == 'gj' else 'Cholesky'}"
+                      f" (C, OpenMP {cores} threads, schedule(dynamic,8)), {dt:.1f} s"}
 
 
 def load_traffic(kernel_name, n):
@@ -110,6 +114,7 @@ def main():
     ap.add_argument("--batch", type=int, default=100_000, help="matrices per GPU per step")
     ap.add_argument("--kernel", default="auto", choices=["auto", "lds", "rowlane", "tile"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other single-GPU workloads")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,13 +124,21 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; MATINV_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed on a single-GPU box (ranks then
+    # share the device and the collectives run through host memory)
+    backend = os.environ.get("MATINV_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    coll_dev = device if backend == "nccl" else torch.device("cpu")
 
     api = importlib.import_module(PKG + ".api")
     n, algo_name, desc = WORKLOADS[args.workload]
@@ -164,14 +177,15 @@ def main():
 
     gather_ms = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, kern_ms = float(t[0].item()), float(t[1].item())
         shard = importlib.import_module(PKG + ".shard")
         torch.cuda.synchronize()
         dist.barrier()
         g0 = time.perf_counter()
-        full = shard.all_gather_shards(x, n, batch * world)
+        # result reassembly on every rank (RCCL all-gather over xGMI); host staging only in the gloo rehearsal
+        full = shard.all_gather_shards(x if backend == "nccl" else x.cpu(), n, batch * world)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert full.numel() == batch * world * n * n
@@ -182,6 +196,32 @@ def main():
     xm = x.view(batch, n, n)[:8]
     resid = float((torch.bmm(am, xm) - torch.eye(n, dtype=a.dtype, device=device)).abs().max())
     assert resid < 1e-11 * n, f"residual {resid}"
+
+    others = {}
+    if rank == 0 and world == 1 and not args.no_others:
+        # the other single-GPU configs of BASELINE.json, a few launches each (same timing method), for the record
+        del a, x
+        for wname in ("gj16", "chol64", "gj32", "gj8", "gj128"):
+            if wname == args.workload:
+                continue
+            n2, algo2_name, _ = WORKLOADS[wname]
+            algo2 = api.ALGO_GAUSS_JORDAN if algo2_name == "gj" else api.ALGO_CHOLESKY
+            b2 = min(batch, 25_000) if n2 >= 128 else batch
+            a2 = make_spd(n2, b2, 0x5EED + 17 * n2, device)
+            x2 = torch.empty_like(a2)
+            for _ in range(2):
+                api.inverse_batched(a2, n2, algo2, out=x2, batch=b2)
+            ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+            for s_, e_ in ev2:
+                s_.record()
+                api.inverse_batched(a2, n2, algo2, out=x2, batch=b2)
+                e_.record()
+            torch.cuda.synchronize()
+            ms2 = float(np.mean([s_.elapsed_time(e_) for s_, e_ in ev2]))
+            gbs = b2 * 2 * n2 * n2 * 8 / (ms2 * 1e-3) / 1e9
+            others[wname] = {"kernel": api.kernel_name(algo2, api.F64, n2), "batch": b2, "kernel_ms": ms2,
+                             "inversions_per_s": b2 / (ms2 * 1e-3), "GB_per_s": gbs, "frac": gbs / HBM_PEAK_GBS}
+            del a2, x2
 
     if rank == 0:
         total = batch * world * args.steps
@@ -202,6 +242,8 @@ def main():
         }
         if gather_ms is not None:
             out["allgather_ms"] = gather_ms
+        if others:
+            out["other_workloads"] = others
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, algo_name)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_pmc_counters.txt (written by tools/pmc_dump.py) -> profiles/traffic.json: HBM bytes per launch of
+each matinv kernel = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024.
+Both counters are KiB. Per /opt/skills/guides/MI355X_MICROARCH.md (section HBM) FETCH_SIZE on gfx950 reports exactly half
+of the bytes of a coalesced streaming read (TCC_EA0_RDREQ tallied at 64 B for 128-B requests) and WRITE_SIZE is exact;
+both factors were re-checked here on a known byte count: matinv_gj_tile_f64 reads every input element exactly once, and
+2 * FETCH_SIZE * 1024 / (batch * n * n * 8) = 1.0002.
+usage: pmc_to_traffic.py profiles/r01_pmc_counters.txt batch"""
+import json
+import os
+import re
+import sys
+
+src, batch = sys.argv[1], int(sys.argv[2])
+vals = {}
+for ln in open(src):
+    if ln.startswith("#") or ln.startswith("pass"):
+        continue
+    f = ln.split(None, 4)
+    if len(f) < 5 or f[1] not in ("FETCH_SIZE", "WRITE_SIZE"):
+        continue
+    vals.setdefault(f[4].strip(), {})[f[1]] = float(f[2])
+path = os.path.join(os.path.dirname(src), "traffic.json")
+table = {}
+for kern, v in vals.items():
+    if "worklist" in kern or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        continue
+    m = re.search(r"<(?:double, )?(\d+)", kern)
+    rd, wr = 2.0 * v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
+    n = {"matinv_gj_tile_f64": 16, "matinv_spd_tile_f64": 16, "matinv_gj_tile4_f64": 16}.get(kern.split("<")[0], 1) * int(m.group(1))
+    table[f"{kern}|n={n}"] = rd + wr
+    table[f"{kern}|n={n}|detail"] = {"batch": batch, "read_bytes": rd, "write_bytes": wr,
+                                     "algorithmic_bytes": batch * 2 * n * n * 8,
+                                     "traffic_over_algorithmic": (rd + wr) / (batch * 2 * n * n * 8), "source": os.path.basename(src)}
+json.dump(table, open(path, "w"), indent=1, sort_keys=True)
+for k, v in table.items():
+    if not k.endswith("detail"):
+        print(k, v, table[k + "|detail"]["traffic_over_algorithmic"])
