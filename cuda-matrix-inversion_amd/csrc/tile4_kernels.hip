@@ -8,8 +8,11 @@
 //   * A operand = -W[:,K] D^-1 is needed by every wave: the wave that owns tile column kb/4 stages the 4 pivot columns
 //     in LDS (4 KB), then all four waves solve the 4x4 pivot block redundantly and form the same Aop (no second
 //     exchange, and the acceptance flag comes out identical in every wave).
-// Two workgroup barriers per block step (panel visible / panel consumed). Rejected matrices (a multiplier above TAU)
-// go to the same device work list and are redone by the pivoted LDS kernel, which handles n <= 141.
+// Look-ahead: every wave first updates the local tile column that (for the next owner) holds the next pivot columns, the
+// next owner stages them into the OTHER half of a double-buffered LDS panel, one workgroup barrier, then the remaining
+// MFMAs run pinned between the stages of the next panel's solve. One barrier per block step.
+// Rejected matrices (a multiplier above TAU) go to the same device work list and are redone by the pivoted LDS kernel,
+// which handles n <= 141.
 //
 // Replaces, for 64 < n <= 128, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95.
 #include "tile_common.hpp"
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(64 * T4_WAVES, FULL ? 2 : 1) void matinv_gj_tile4_f
     constexpr int NKB = 4 * NT;
     constexpr int NC = (NT + T4_WAVES - 1) / T4_WAVES;
     const int n = FULL ? N : n_rt;
-    __shared__ __attribute__((aligned(16))) double panel[N * 4];  // [row][4 pivot columns]
+    __shared__ __attribute__((aligned(16))) double panel[2 * N * 4];  // double buffered [row][4 pivot columns]
     const int l = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;  // wave-uniform
 
@@ -55,6 +58,25 @@ __global__ __launch_bounds__(64 * T4_WAVES, FULL ? 2 : 1) void matinv_gj_tile4_f
                 }
             }
         unsigned long long bad = 0;
+        double aop[NT], bop[NC];
+
+        // Look-ahead pipeline with ONE workgroup barrier per block step (the panel is double buffered in LDS):
+        //   every wave updates its local column jo_n first (for the next owner that is the column holding the next
+        //   pivot columns); the next owner stages them; barrier; the other local column is updated while every wave
+        //   solves the next panel (MFMAs pinned between the solve stages).
+        auto stage_panel = [&](int kb) {
+            const int tK = kb >> 2, c0 = 4 * (kb & 3), jo = tK / T4_WAVES;
+            double *buf = panel + (kb & 1) * (N * 4);
+            if (w == tK % T4_WAVES && c >= c0 && c < c0 + 4) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) buf[(16 * ti + 4 * r + q) * 4 + (c - c0)] = acc[ti][jo][r];
+            }
+        };
+        stage_panel(0);
+        __syncthreads();
+        panel_solve<NT>(panel, 0, q, c, aop, bad);
 
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -62,24 +84,11 @@ __global__ __launch_bounds__(64 * T4_WAVES, FULL ? 2 : 1) void matinv_gj_tile4_f
             const int owner = tK % T4_WAVES, jo = tK / T4_WAVES;  // wave and local column holding the pivot columns
             const bool panel_lane = (c >= c0) && (c < c0 + 4);
             const bool diag_lane = panel_lane && (c - c0 == q);
-            // 1. the owner stages the 4 pivot columns, [row][4]
-            if (w == owner && panel_lane) {
-#pragma unroll
-                for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) panel[(16 * ti + 4 * r + q) * 4 + (c - c0)] = acc[ti][jo][r];
-            }
-            __syncthreads();
-            // 2.-4. every wave: D^-1 (column q) and the A operand of all NT tile rows
-            double aop[NT];
-            panel_solve<NT>(panel, kb, q, c, aop, bad);
-            __syncthreads();  // panel consumed: the next owner may overwrite it
-            // 5. B operand: pivot rows of the wave's own columns; I_4 on the pivot columns (owner only)
-            double bop[NC];
+            // B operand: pivot rows of the wave's own columns; I_4 on the pivot columns (owner only)
 #pragma unroll
             for (int jl = 0; jl < NC; ++jl) bop[jl] = acc[tK][jl][rK];
             if (w == owner) bop[jo] = panel_lane ? (diag_lane ? 1.0 : 0.0) : bop[jo];
-            // 6. C operand: zero on the pivot columns (owner) and on the pivot rows (everyone)
+            // C operand: zero on the pivot columns (owner) and on the pivot rows (everyone)
             if (w == owner) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
@@ -88,13 +97,61 @@ __global__ __launch_bounds__(64 * T4_WAVES, FULL ? 2 : 1) void matinv_gj_tile4_f
             }
 #pragma unroll
             for (int jl = 0; jl < NC; ++jl) acc[tK][jl][rK] = 0.0;
-            // 7. rank-4 update of the wave's tiles
+
+            if (kb + 1 < NKB) {
+                const int jn = ((kb + 1) >> 2) / T4_WAVES;  // local column updated first
 #pragma unroll
-            for (int ti = 0; ti < NT; ++ti)
+                for (int ti = 0; ti < NT; ++ti)
+                    acc[ti][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[jn], acc[ti][jn], 0, 0, 0);
+                stage_panel(kb + 1);
+#ifndef TILE_DBG_NO_BARRIER
+                __syncthreads();
+#endif
+                const double *pnext = panel + ((kb + 1) & 1) * (N * 4);
+                constexpr int NS = PanelSolve<NT>::NSTAGE;
+                constexpr int NB = NT * (NC - 1);
+                double aop_next[NT];
+                PanelSolve<NT> ps;
+                int count = 0, ev = 0;
+                auto run_events = [&](bool flush) {
 #pragma unroll
-                for (int jl = 0; jl < NC; ++jl)
-                    acc[ti][jl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[jl], acc[ti][jl], 0, 0, 0);
+                    for (int e = 0; e < NS; ++e) {
+                        const int thr = (NB * e) / NS;
+                        if (e == ev && (flush || thr <= count)) {
+                            __builtin_amdgcn_sched_barrier(0);
+#ifndef TILE_DBG_NO_PANEL
+                            ps.stage(e, pnext, kb + 1, q, c, aop_next, bad);
+#else
+                            if (e >= 6) aop_next[e - 6] = aop[e - 6] * 0.5 + pnext[(16 * (e - 6) + c) * 4];
+#endif
+                            __builtin_amdgcn_sched_barrier(0);
+                            ++ev;
+                        }
+                    }
+                };
+                run_events(false);
+#pragma unroll
+                for (int jl = 0; jl < NC; ++jl) {
+                    if (jl == jn) continue;
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti) {
+                        acc[ti][jl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[jl], acc[ti][jl], 0, 0, 0);
+                        ++count;
+                        run_events(false);
+                    }
+                }
+                run_events(true);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) aop[ti] = aop_next[ti];
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int jl = 0; jl < NC; ++jl)
+                        acc[ti][jl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[jl], acc[ti][jl], 0, 0, 0);
+            }
         }
+        __syncthreads();  // both panel buffers are free again before the next matrix stages its first panel
 
         if (bad == 0) {  // identical in all four waves (they evaluate the same D and the same Aop)
 #pragma unroll
