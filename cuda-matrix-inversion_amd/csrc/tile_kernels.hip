@@ -40,47 +40,48 @@ namespace matinv {
 // ---- pieces of one block step ---------------------------------------------------------------------------------
 
 // 1. the 4 pivot columns of block kb -> LDS, [row][4]. They live in the 16 lanes c in [c0, c0+4) of tile column tK.
-template <int NT>
-__device__ __forceinline__ void panel_to_lds(double *panel, const v4d (&acc)[NT][NT], int kb, int q, int c)
+template <int NT, class T>
+__device__ __forceinline__ void panel_to_lds(T *panel, const typename TileGeo<T>::vec4 (&acc)[NT][NT], int kb, int q, int c)
 {
-    const int tK = kb >> 2, c0 = 4 * (kb & 3);
-    if (c >= c0 && c < c0 + 4) {
+    typedef TileGeo<T> G;
+    const int tK = kb >> 2, rK = kb & 3;
+    if (G::blk(c) == rK) {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) panel[(16 * ti + 4 * r + q) * 4 + (c - c0)] = acc[ti][tK][r];
+            for (int r = 0; r < 4; ++r) panel[(16 * ti + G::trow(r, q)) * 4 + G::piv(c)] = acc[ti][tK][r];
     }
 }
 
 // 5.+6. B operand (pivot rows as they stand, I_4 on the pivot columns) and C operand (zero on the pivot columns: the
 // MFMA then leaves Aop * I_4 = the new K columns there; zero on the pivot rows: they become D^-1 * W[K,:], a pure
 // product -- no cancellation, and the step stays exactly equivariant under power-of-two scaling of the input).
-template <int NT>
-__device__ __forceinline__ void prep_operands(v4d (&acc)[NT][NT], double (&bop)[NT], int kb, int q, int c)
+template <int NT, class T>
+__device__ __forceinline__ void prep_operands(typename TileGeo<T>::vec4 (&acc)[NT][NT], T (&bop)[NT], int kb, int q, int c)
 {
-    const int tK = kb >> 2, rK = kb & 3, c0 = 4 * (kb & 3);
-    const bool panel_lane = (c >= c0) && (c < c0 + 4);
-    const bool diag_lane = panel_lane && (c - c0 == q);
+    typedef TileGeo<T> G;
+    const int tK = kb >> 2, rK = kb & 3;
+    const bool panel_lane = G::blk(c) == rK;
+    const bool diag_lane = panel_lane && (G::piv(c) == q);
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) bop[tj] = acc[tK][tj][rK];
-    bop[tK] = panel_lane ? (diag_lane ? 1.0 : 0.0) : bop[tK];
+    bop[tK] = panel_lane ? (diag_lane ? (T)1 : (T)0) : bop[tK];
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ti][tK][r] = panel_lane ? 0.0 : acc[ti][tK][r];
+        for (int r = 0; r < 4; ++r) acc[ti][tK][r] = panel_lane ? (T)0 : acc[ti][tK][r];
 #pragma unroll
-    for (int tj = 0; tj < NT; ++tj) acc[tK][tj][rK] = 0.0;
+    for (int tj = 0; tj < NT; ++tj) acc[tK][tj][rK] = (T)0;
 }
 
-// FULL: n == 16*NT known at compile time (constant address offsets, no bounds checks).
-// LOOKAHEAD: software pipelining across block steps -- the tile column that holds the NEXT pivot columns is updated
-// first, the next panel is extracted and solved while the remaining MFMAs of the current step are in flight.
-template <int NT, bool FULL, bool LOOKAHEAD>
-__global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f64(BatchRef<const double> Ain,
-                                                                                 BatchRef<double> Xout, int *info,
-                                                                                 int n_rt, unsigned batch,
-                                                                                 int *work_count, int *work_list)
+// One matrix per wavefront; see the file header. T = double or float.
+template <class T, int NT, bool FULL, bool LOOKAHEAD>
+__device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
+                                             int *work_count, int *work_list, T *panel)
 {
+    typedef TileGeo<T> G;
+    typedef typename G::vec4 vec4;
+    typedef typename G::vec2 vec2;
     constexpr int N = 16 * NT;
     constexpr int NKB = 4 * NT;
     // PAIRED: 16-byte global accesses. The labels (tile, register, lane) -> (matrix row, matrix column) are ours to
@@ -92,32 +93,31 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
     // depends on the relabelling (a symmetric permutation of the matrix: inv(P A P^T) = P inv(A) P^T).
     constexpr bool PAIRED = FULL && (NT % 2 == 0);
     const int n = FULL ? N : n_rt;
-    __shared__ __attribute__((aligned(16))) double panel[N * 4];  // [row][4 pivot columns]
     const int l = threadIdx.x;
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
-        const double *A = Ain.at(mat);
-        double *X = Xout.at(mat);
+        const T *A = Ain.at(mat);
+        T *X = Xout.at(mat);
         // Launder the lane coordinates once per matrix: otherwise LICM hoists the ~60 per-lane constants of the 4*NT
         // unrolled block steps (I_4 lanes, e_q entries, lane masks) out of this loop and the allocator spills them.
         int q = l >> 4, c = l & 15;
         // (addresses keep using the un-laundered lane id so they stay in saddr + 32-bit voffset + immediate form)
-        const unsigned lane_off = (unsigned)((l >> 4) * n + (l & 15));
+        const unsigned lane_off = (unsigned)(G::trow(0, l >> 4) * n + (l & 15));
         asm volatile("" : "+v"(q), "+v"(c));
         // one per-lane element offset + wave-uniform (compile-time when FULL) tile offsets keep the 16*NT*NT
         // addresses out of VGPRs
-        v4d acc[NT][NT];
+        vec4 acc[NT][NT];
         if (PAIRED) {
             // 16-byte accesses: see the index relabelling above (rows/cols of tile pairs interleaved by parity)
-            const unsigned lane_off2 = (unsigned)(2 * (l >> 4) * N + 2 * (l & 15));
+            const unsigned lane_off2 = (unsigned)(2 * G::trow(0, l >> 4) * N + 2 * (l & 15));
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int u = 0; u < NT / 2; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const unsigned uoff = (unsigned)((32 * (ti >> 1) + 8 * r + (ti & 1)) * N + 32 * u);
-                        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(A + uoff + lane_off2));
+                        const unsigned uoff = (unsigned)((32 * (ti >> 1) + 2 * G::trow(r, 0) + (ti & 1)) * N + 32 * u);
+                        const vec2 v = __builtin_nontemporal_load(reinterpret_cast<const vec2 *>(A + uoff + lane_off2));
                         acc[ti][2 * u][r] = v[0];
                         acc[ti][2 * u + 1][r] = v[1];
                     }
@@ -128,14 +128,14 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
                 for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                        const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
                         // identity padding beyond n: blockdiag(A, I)^-1 = blockdiag(A^-1, I)
-                        const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
-                        acc[ti][tj][r] = (FULL || (row < n && col < n)) ? A[uoff + lane_off] : ((row == col) ? 1.0 : 0.0);
+                        const unsigned uoff = (unsigned)((16 * ti + G::trow(r, 0)) * n + 16 * tj);
+                        acc[ti][tj][r] = (FULL || (row < n && col < n)) ? A[uoff + lane_off] : ((row == col) ? (T)1 : (T)0);
                     }
         }
         unsigned long long bad = 0;  // wave-uniform: lanes that saw a multiplier above TAU (or NaN)
-        double aop[NT], bop[NT];
+        T aop[NT], bop[NT];
 
 #ifdef TILE_DBG_REPEAT
         for (int rep_ = 0; rep_ < TILE_DBG_REPEAT; ++rep_)
@@ -145,18 +145,18 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
 #else
         if (LOOKAHEAD) {
 #endif
-            panel_to_lds<NT>(panel, acc, 0, q, c);
+            panel_to_lds<NT, T>(panel, acc, 0, q, c);
             __syncthreads();
             panel_solve<NT>(panel, 0, q, c, aop, bad);
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                prep_operands<NT>(acc, bop, kb, q, c);
+                prep_operands<NT, T>(acc, bop, kb, q, c);
                 if (kb + 1 < NKB) {
                     const int tn = (kb + 1) >> 2;
                     // (a) the tile column holding the next pivot columns first ...
 #pragma unroll
                     for (int ti = 0; ti < NT; ++ti)
-                        acc[ti][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tn], acc[ti][tn], 0, 0, 0);
+                        acc[ti][tn] = G::mfma(aop[ti], bop[tn], acc[ti][tn]);
                     // (b) the other NT*(NT-1) tiles, pinned in program order between the pieces of the next
                     //     panel: 2 MFMAs cover the latency of (a) before the panel columns are read back, then one
                     //     MFMA after every stage. sched_barrier(0) keeps hipcc from re-clustering them.
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
                                 const int tjx = pend / NT, ti = pend % NT;
                                 const int tj = tjx + (tjx >= tn ? 1 : 0);
 #ifndef TILE_DBG_NO_MFMA
-                                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc[ti][tj], 0, 0, 0);
+                                acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
 #else
                                 acc[ti][tj][0] += aop[ti] * bop[tj];
 #endif
@@ -181,12 +181,12 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
                     __builtin_amdgcn_sched_barrier(0);
                     issue_b(2);
                     __syncthreads();  // panel(kb) has been consumed (aop is in registers)
-                    panel_to_lds<NT>(panel, acc, kb + 1, q, c);
+                    panel_to_lds<NT, T>(panel, acc, kb + 1, q, c);
                     __syncthreads();
                     __builtin_amdgcn_sched_barrier(0);
-                    double aop_next[NT];
-                    PanelSolve<NT> ps;
-                    constexpr int NS = PanelSolve<NT>::NSTAGE;
+                    T aop_next[NT];
+                    PanelSolve<NT, false, T> ps;
+                    constexpr int NS = PanelSolve<NT, false, T>::NSTAGE;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         // spread the remaining MFMAs evenly over the stages
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
                     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                         for (int tj = 0; tj < NT; ++tj)
-                            acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc[ti][tj], 0, 0, 0);
+                            acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
                 }
             }
         } else {
@@ -220,17 +220,17 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
                 NKB
 #endif
                 ); ++kb) {
-                panel_to_lds<NT>(panel, acc, kb, q, c);
+                panel_to_lds<NT, T>(panel, acc, kb, q, c);
                 __syncthreads();
                 panel_solve<NT>(panel, kb, q, c, aop, bad);
                 __syncthreads();  // panel is rewritten by the next block step
-                prep_operands<NT>(acc, bop, kb, q, c);
+                prep_operands<NT, T>(acc, bop, kb, q, c);
                 // 7. rank-4 update of every tile on the matrix cores
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < NT; ++tj)
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc[ti][tj], 0, 0, 0);
+                        acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
             }
         }
 
@@ -239,18 +239,18 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
 #endif
         if (bad == 0) {
             if (PAIRED) {
-                const unsigned lane_off2 = (unsigned)(2 * (l >> 4) * N + 2 * (l & 15));
+                const unsigned lane_off2 = (unsigned)(2 * G::trow(0, l >> 4) * N + 2 * (l & 15));
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                     for (int u = 0; u < NT / 2; ++u)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const unsigned uoff = (unsigned)((32 * (ti >> 1) + 8 * r + (ti & 1)) * N + 32 * u);
-                            v2d v;
+                            const unsigned uoff = (unsigned)((32 * (ti >> 1) + 2 * G::trow(r, 0) + (ti & 1)) * N + 32 * u);
+                            vec2 v;
                             v[0] = acc[ti][2 * u][r];
                             v[1] = acc[ti][2 * u + 1][r];
-                            __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(X + uoff + lane_off2));
+                            __builtin_nontemporal_store(v, reinterpret_cast<vec2 *>(X + uoff + lane_off2));
                         }
             } else {
 #pragma unroll
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
                     for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
-                            const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
+                            const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
+                            const unsigned uoff = (unsigned)((16 * ti + G::trow(r, 0)) * n + 16 * tj);
                             if (FULL || (row < n && col < n)) X[uoff + lane_off] = acc[ti][tj][r];
                         }
             }
@@ -271,6 +271,30 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
         }
         if (LOOKAHEAD) __syncthreads();  // the next matrix's first panel write must not pass this one's last reads
     }
+}
+
+
+// FULL: n == 16*NT known at compile time (constant address offsets, no bounds checks).
+// LOOKAHEAD: software pipelining across block steps -- the tile column that holds the NEXT pivot columns is updated
+// first, the next panel is extracted and solved while the remaining MFMAs of the current step are in flight.
+template <int NT, bool FULL, bool LOOKAHEAD>
+__global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f64(BatchRef<const double> Ain,
+                                                                                 BatchRef<double> Xout, int *info,
+                                                                                 int n_rt, unsigned batch,
+                                                                                 int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) double panel[16 * NT * 4];  // [row][4 pivot columns]
+    gj_tile_body<double, NT, FULL, LOOKAHEAD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
+}
+
+// fp32 (the reference's DataType): v_mfma_f32_16x16x4_f32, 4 VGPRs per tile (64 at n = 64), same algorithm; the pivot
+// blocks follow the f32 accumulator layout (TileGeo<float>).
+template <int NT, bool FULL, bool LOOKAHEAD>
+__global__ __launch_bounds__(64, 4) void matinv_gj_tile_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
+                                                           int n_rt, unsigned batch, int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) float panel[16 * NT * 4];
+    gj_tile_body<float, NT, FULL, LOOKAHEAD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
 }
 
 // ================================================================================================================
@@ -458,15 +482,41 @@ bool tile_family_supports(int n);
 template <>
 bool tile_family_supports<double>(int n) { return n >= 1 && n <= 128; }
 template <>
-bool tile_family_supports<float>(int) { return false; }
+bool tile_family_supports<float>(int n) { return n >= 1 && n <= 64; }
 
 template <class T>
 hipError_t launch_gj_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 
 template <>
-hipError_t launch_gj_tile<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t)
+hipError_t launch_gj_tile<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info,
+                                 hipStream_t stream)
 {
-    return hipErrorInvalidValue;
+    if (!tile_family_supports<float>(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int nt = (n + 15) / 16;
+    const unsigned grid = (unsigned)(batch < 256u * 16u * 4u ? batch : 256u * 16u * 4u);
+    const unsigned b = (unsigned)batch;
+#define TILE_LAUNCH_F32(NT_)                                                                                          \
+    if (n == 16 * NT_)                                                                                                \
+        hipLaunchKernelGGL((matinv_gj_tile_f32<NT_, true, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((matinv_gj_tile_f32<NT_, false, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1)
+    switch (nt) {
+    case 1: TILE_LAUNCH_F32(1); break;
+    case 2: TILE_LAUNCH_F32(2); break;
+    case 3: TILE_LAUNCH_F32(3); break;
+    default: TILE_LAUNCH_F32(4); break;
+    }
+#undef TILE_LAUNCH_F32
+    e = hipGetLastError();
+    if (e == hipSuccess) e = launch_gj_lds_worklist<float>(n, A, X, ws, ws + 1, info, stream);
+    hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
 }
 
 template <>
@@ -570,7 +620,15 @@ const char *name_spd_tile(bool f64, int n)
 
 const char *name_gj_tile(bool f64, int n)
 {
-    if (!f64) return "";
+    if (!f64) {
+        const bool fullf = (n % 16) == 0;
+        switch ((n + 15) / 16) {
+        case 1: return fullf ? "matinv_gj_tile_f32<1, true, true>" : "matinv_gj_tile_f32<1, false, false>";
+        case 2: return fullf ? "matinv_gj_tile_f32<2, true, true>" : "matinv_gj_tile_f32<2, false, false>";
+        case 3: return fullf ? "matinv_gj_tile_f32<3, true, true>" : "matinv_gj_tile_f32<3, false, false>";
+        default: return fullf ? "matinv_gj_tile_f32<4, true, true>" : "matinv_gj_tile_f32<4, false, false>";
+        }
+    }
     if (n > 64) return name_gj_tile4_f64(n);
     const bool full = (n % 16) == 0;
     switch ((n + 15) / 16) {

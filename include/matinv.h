@@ -52,9 +52,9 @@ typedef enum {
     MATINV_KERNEL_AUTO = 0,
     MATINV_KERNEL_LDS = 1,     /* one workgroup per matrix, matrix resident in LDS, any n up to the LDS limit */
     MATINV_KERNEL_ROWLANE = 2, /* n <= 16: 64/npad matrices per wavefront, one row per lane, DPP broadcasts     */
-    MATINV_KERNEL_TILE = 3     /* f64, 16x16 fp64 MFMA accumulator tiles: blocked Gauss-Jordan with one wavefront per matrix
-                                  (n <= 64) or four (64 < n <= 128); for MATINV_ALGO_CHOLESKY the symmetric blocked sweep on
-                                  lower-triangular tiles (n <= 64) */
+    MATINV_KERNEL_TILE = 3     /* 16x16 MFMA accumulator tiles: blocked Gauss-Jordan with one wavefront per matrix (n <= 64,
+                                  f64 and f32) or four (64 < n <= 128, f64); for MATINV_ALGO_CHOLESKY the symmetric blocked
+                                  sweep on lower-triangular tiles (n <= 64, f64) */
 } matinv_kernel;
 
 /* Invert `batch` matrices that are already resident in device memory.
