@@ -3,20 +3,25 @@
 // A wavefront holds 64/NP matrices (NP = 8 or 16 = n rounded up, identity padded): lane (g, i) owns row i of
 // matrix g, register c holds column c, so the load `a[c] = A[c*n + i]` is a coalesced 8*NP-byte segment per matrix
 // and consecutive matrices of the batch are adjacent in the wave. In-place Gauss-Jordan with partial (row) pivoting:
-//   * pivot search   = max-reduction of |a[k]| over the NP lanes of the matrix with DPP quad_perm / row_half_mirror /
-//                      row_mirror (no LDS), ballot + ctz for the pivot lane;
-//   * pivot row      = brought to lane k (ds_bpermute row swap, only when some matrix of the wave needs it -- never on
-//                      diagonally dominant input) and then broadcast with DPP row_newbcast:k straight into the FMA operand;
-//   * elimination    = NP fused multiply-adds per lane per step, multiplier lane-local.
+//   * pivot choice   = threshold partial pivoting: the diagonal entry is kept while no multiplier exceeds 4; otherwise the
+//                      column maximum is found by a DPP max-reduction of |a[k]| over the NP lanes of the matrix (quad_perm /
+//                      row_half_mirror / row_mirror, no LDS) + ballot + ctz and brought to lane k with a ds_bpermute row swap
+//                      (wave-uniform branch; never taken on diagonally dominant input);
+//   * pivot row      = broadcast with DPP row_newbcast:k straight into the FMA operand;
+//   * elimination    = NP-1 fused multiply-adds per lane per step, multiplier lane-local; the pivot rows stay unscaled
+//                      until one final multiply per element.
 // Row swaps are undone as a column permutation folded into the store addresses.
 //
 // Replaces, for small n, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95 (pivotRow :17-45,
 // normalizeRow :47-57, transform_matrix :59-82) with one launch that touches HBM once per element.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace matinv {
 
 constexpr int ROWLANE_THREADS = 256;
+constexpr double ROWLANE_TAU = 4.0;  // a diagonal pivot is accepted while every multiplier is <= TAU (threshold pivoting)
 
 // DPP controls (LLVM AMDGPU DppCtrl encoding)
 constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
@@ -67,11 +72,11 @@ __device__ __forceinline__ V bcast_lane(V v, int k)
 //   for every column c != K:  a[c] += a_pivotrow[c] * negm      (v_fmac_*_dpp: the DPP row broadcast of lane K is
 //                                                                folded into the FMA operand -- hipcc does not form
 //                                                                this from __builtin_amdgcn_update_dpp)
-//   for every column c != K:  a[c] *= scale                      (1/pivot on the pivot row, 1.0 elsewhere)
-// The pivot row has negm = 0, so the broadcast always reads the UNSCALED pivot row. Hazards: the ISA wants 2 wait
-// states between a VALU write of a VGPR and a DPP read of it, and hipcc pads nothing inside or before an asm block:
-// the leading `s_nop 1` covers whatever VALU instruction the compiler scheduled last; inside the block a register is
-// DPP-read (first loop) strictly before it is written again (its own fmac, then the multiply loop).
+// The pivot row has negm = 0 and is left UNSCALED for the whole elimination (its 1/pivot is applied once, at the end:
+// later steps treat it like any other row and row scaling commutes with row operations), so there is no per-step
+// normalisation pass. Hazards: the ISA wants 2 wait states between a VALU write of a VGPR and a DPP read of it, and hipcc
+// pads nothing inside or before an asm block: the leading `s_nop 1` covers whatever VALU instruction the compiler
+// scheduled last; inside the block every register is DPP-read by the one instruction that also rewrites it.
 #define RL_FMAC16(T_, c) \
     ".if %[k] != " #c "\n\tv_fmac_" T_ "_dpp %[a" #c "], %[a" #c "], %[m] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t.endif\n\t"
 // NP = 8: two matrices share a DPP row of 16 lanes. 64-bit DPP ignores bank_mask (measured on gfx950: both halves were
@@ -86,9 +91,7 @@ __device__ __forceinline__ V bcast_lane(V v, int k)
     RL_8(RL_FMAC8_LO, T_)                                                                                             \
     "s_mov_b32 exec_lo, 0xff00ff00\n\ts_mov_b32 exec_hi, 0xff00ff00\n\ts_nop 1\n\t"                                  \
     RL_8(RL_FMAC8_HI, T_)                                                                                             \
-    "s_mov_b64 exec, %[sv]\n\t"                                                                                       \
-    RL_8(RL_MUL, T_)
-#define RL_MUL(T_, c) ".if %[k] != " #c "\n\tv_mul_" T_ " %[a" #c "], %[a" #c "], %[s]\n\t.endif\n\t"
+    "s_mov_b64 exec, %[sv]\n\t"
 #define RL_8(M, T_) M(T_, 0) M(T_, 1) M(T_, 2) M(T_, 3) M(T_, 4) M(T_, 5) M(T_, 6) M(T_, 7)
 #define RL_16(M, T_) RL_8(M, T_) M(T_, 8) M(T_, 9) M(T_, 10) M(T_, 11) M(T_, 12) M(T_, 13) M(T_, 14) M(T_, 15)
 #define RL_OPS8 [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]), [a5] "+v"(a[5]), \
@@ -97,64 +100,64 @@ __device__ __forceinline__ V bcast_lane(V v, int k)
                  [a13] "+v"(a[13]), [a14] "+v"(a[14]), [a15] "+v"(a[15])
 
 template <int K>
-__device__ __forceinline__ void elim_step_const(double (&a)[16], double negm, double scale)
+__device__ __forceinline__ void elim_step_const(double (&a)[16], double negm)
 {
-    asm volatile("s_nop 1\n\t" RL_16(RL_FMAC16, "f64") RL_16(RL_MUL, "f64")
-                 : RL_OPS16 : [m] "v"(negm), [s] "v"(scale), [k] "n"(K));
+    asm volatile("s_nop 1\n\t" RL_16(RL_FMAC16, "f64")
+                 : RL_OPS16 : [m] "v"(negm), [k] "n"(K));
 }
 template <int K>
-__device__ __forceinline__ void elim_step_const(float (&a)[16], float negm, float scale)
+__device__ __forceinline__ void elim_step_const(float (&a)[16], float negm)
 {
-    asm volatile("s_nop 1\n\t" RL_16(RL_FMAC16, "f32") RL_16(RL_MUL, "f32")
-                 : RL_OPS16 : [m] "v"(negm), [s] "v"(scale), [k] "n"(K));
+    asm volatile("s_nop 1\n\t" RL_16(RL_FMAC16, "f32")
+                 : RL_OPS16 : [m] "v"(negm), [k] "n"(K));
 }
 template <int K>
-__device__ __forceinline__ void elim_step_const(double (&a)[8], double negm, double scale)
+__device__ __forceinline__ void elim_step_const(double (&a)[8], double negm)
 {
     unsigned long long sv;
-    asm volatile(RL_STEP8("f64") : RL_OPS8, [sv] "=&s"(sv) : [m] "v"(negm), [s] "v"(scale), [k] "n"(K), [k8] "n"(K + 8));
+    asm volatile(RL_STEP8("f64") : RL_OPS8, [sv] "=&s"(sv) : [m] "v"(negm), [k] "n"(K), [k8] "n"(K + 8));
 }
 template <int K>
-__device__ __forceinline__ void elim_step_const(float (&a)[8], float negm, float scale)
+__device__ __forceinline__ void elim_step_const(float (&a)[8], float negm)
 {
     unsigned long long sv;
-    asm volatile(RL_STEP8("f32") : RL_OPS8, [sv] "=&s"(sv) : [m] "v"(negm), [s] "v"(scale), [k] "n"(K), [k8] "n"(K + 8));
+    asm volatile(RL_STEP8("f32") : RL_OPS8, [sv] "=&s"(sv) : [m] "v"(negm), [k] "n"(K), [k8] "n"(K + 8));
 }
 
 template <class T>
-__device__ __forceinline__ void elim_step(T (&a)[8], T negm, T scale, int k)
+__device__ __forceinline__ void elim_step(T (&a)[8], T negm, int k)
 {
     switch (k) {
-    case 0: elim_step_const<0>(a, negm, scale); break;
-    case 1: elim_step_const<1>(a, negm, scale); break;
-    case 2: elim_step_const<2>(a, negm, scale); break;
-    case 3: elim_step_const<3>(a, negm, scale); break;
-    case 4: elim_step_const<4>(a, negm, scale); break;
-    case 5: elim_step_const<5>(a, negm, scale); break;
-    case 6: elim_step_const<6>(a, negm, scale); break;
-    default: elim_step_const<7>(a, negm, scale); break;
+    case 0: elim_step_const<0>(a, negm); break;
+    case 1: elim_step_const<1>(a, negm); break;
+    case 2: elim_step_const<2>(a, negm); break;
+    case 3: elim_step_const<3>(a, negm); break;
+    case 4: elim_step_const<4>(a, negm); break;
+    case 5: elim_step_const<5>(a, negm); break;
+    case 6: elim_step_const<6>(a, negm); break;
+    default: elim_step_const<7>(a, negm); break;
     }
 }
 template <class T>
-__device__ __forceinline__ void elim_step(T (&a)[16], T negm, T scale, int k)
+__device__ __forceinline__ void elim_step(T (&a)[16], T negm, int k)
 {
     switch (k) {
-    case 0: elim_step_const<0>(a, negm, scale); break;
-    case 1: elim_step_const<1>(a, negm, scale); break;
-    case 2: elim_step_const<2>(a, negm, scale); break;
-    case 3: elim_step_const<3>(a, negm, scale); break;
-    case 4: elim_step_const<4>(a, negm, scale); break;
-    case 5: elim_step_const<5>(a, negm, scale); break;
-    case 6: elim_step_const<6>(a, negm, scale); break;
-    case 7: elim_step_const<7>(a, negm, scale); break;
-    case 8: elim_step_const<8>(a, negm, scale); break;
-    case 9: elim_step_const<9>(a, negm, scale); break;
-    case 10: elim_step_const<10>(a, negm, scale); break;
-    case 11: elim_step_const<11>(a, negm, scale); break;
-    case 12: elim_step_const<12>(a, negm, scale); break;
-    case 13: elim_step_const<13>(a, negm, scale); break;
-    case 14: elim_step_const<14>(a, negm, scale); break;
-    default: elim_step_const<15>(a, negm, scale); break;
+    case 0: elim_step_const<0>(a, negm); break;
+    case 1: elim_step_const<1>(a, negm); break;
+    case 2: elim_step_const<2>(a, negm); break;
+    case 3: elim_step_const<3>(a, negm); break;
+    case 4: elim_step_const<4>(a, negm); break;
+    case 5: elim_step_const<5>(a, negm); break;
+    case 6: elim_step_const<6>(a, negm); break;
+    case 7: elim_step_const<7>(a, negm); break;
+    case 8: elim_step_const<8>(a, negm); break;
+    case 9: elim_step_const<9>(a, negm); break;
+    case 10: elim_step_const<10>(a, negm); break;
+    case 11: elim_step_const<11>(a, negm); break;
+    case 12: elim_step_const<12>(a, negm); break;
+    case 13: elim_step_const<13>(a, negm); break;
+    case 14: elim_step_const<14>(a, negm); break;
+    default: elim_step_const<15>(a, negm); break;
     }
 }
 
@@ -180,6 +183,9 @@ __device__ __forceinline__ unsigned mag_key(float v) { return __float_as_uint(v)
 __device__ __forceinline__ bool key_not_finite(double, unsigned k) { return k >= 0x7ff00000u; }
 __device__ __forceinline__ bool key_not_finite(float, unsigned k) { return k >= 0x7f800000u; }
 
+__device__ __forceinline__ double absval(double v) { return __builtin_fabs(v); }
+__device__ __forceinline__ float absval(float v) { return __builtin_fabsf(v); }
+
 __device__ __forceinline__ double recip(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -195,8 +201,15 @@ __device__ __forceinline__ float recip(float x)
     return __builtin_fmaf(r, e, r);
 }
 
+// waves per SIMD the register allocator is asked to fit: two register sets (current + prefetched matrices) must stay in
+// VGPRs -- a spilled accumulator costs far more than the lost occupancy (measured at n = 16, f64: 4.7 -> 5.7 TB/s)
+constexpr int rowlane_occupancy(size_t elem, int np, bool full)
+{
+    return elem == 8 ? (np == 16 ? (full ? 3 : 2) : (full ? 5 : 4)) : (np == 16 ? (full ? 5 : 4) : 6);
+}
+
 template <class T, int NP, bool FULL>
-__global__ __launch_bounds__(ROWLANE_THREADS) void matinv_gj_rowlane(BatchRef<const T> Ain, BatchRef<T> Xout, int *info,
+__global__ __launch_bounds__(ROWLANE_THREADS, rowlane_occupancy(sizeof(T), NP, FULL)) void matinv_gj_rowlane(BatchRef<const T> Ain, BatchRef<T> Xout, int *info,
                                                                      int n_rt, unsigned batch)
 {
     constexpr int GPW = 64 / NP;  // matrices per wavefront
@@ -208,50 +221,82 @@ __global__ __launch_bounds__(ROWLANE_THREADS) void matinv_gj_rowlane(BatchRef<co
     const unsigned wave_stride = gridDim.x * waves_per_block;
     const unsigned n_waves = (batch + GPW - 1) / GPW;
 
-    for (unsigned w = wave0; w < n_waves; w += wave_stride) {
+    const bool row_in = FULL || i < n;
+    // Software prefetch: the matrices of the wave's NEXT grid-stride iteration are loaded into a second register set
+    // before the current ones are eliminated, so their HBM latency hides behind ~600 VALU instructions instead of being
+    // exposed once per iteration (the kernel was measured 79 % waiting on memory without it).
+    T nxt[NP];
+    auto load = [&](unsigned w) {
         const unsigned mat = w * GPW + g;
         const bool valid = mat < batch;
         const T *A = Ain.at(valid ? mat : batch - 1);
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+            nxt[c] = (valid && row_in && (FULL || c < n)) ? A[c * n + i] : ((i == c) ? (T)1 : (T)0);
+    };
+    if (wave0 < n_waves) load(wave0);
+
+    for (unsigned w = wave0; w < n_waves; w += wave_stride) {
+        const unsigned mat = w * GPW + g;
+        const bool valid = mat < batch;
         T *X = Xout.at(valid ? mat : batch - 1);
-        const bool row_in = FULL || i < n;
 
         T a[NP];
 #pragma unroll
-        for (int c = 0; c < NP; ++c)
-            a[c] = (valid && row_in && (FULL || c < n)) ? A[c * n + i] : ((i == c) ? (T)1 : (T)0);
+        for (int c = 0; c < NP; ++c) a[c] = nxt[c];
+        if (w + wave_stride < n_waves) load(w + wave_stride);
 
-        int src = i;          // lane j: source column of output column j (composite of the undone row swaps)
-        int bad = 0;          // k+1 of the first step without a usable pivot
+        int src = i;            // lane j: source column of output column j (composite of the undone row swaps)
+        int bad = 0;            // k+1 of the first step without a usable pivot
         bool any_swap = false;  // wave-uniform
+        T rowscale = (T)1;      // 1/pivot of the step in which this lane's row was the pivot row
 
+#ifdef ROWLANE_DBG_NO_COMPUTE
+        for (int k = 0; k < 0; ++k) {
+#else
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            // 1. pivot search in column k over rows >= k of this lane's matrix
-            const unsigned key = (i >= k) ? mag_key(a[k]) : 0u;
-            const unsigned mx = group_max<NP>(key);
-            const bool is_max = (key == mx) && (i >= k);
-            const unsigned long long vote = __ballot(is_max);
-            const unsigned gbits = (unsigned)(vote >> (g * NP)) & ((1u << NP) - 1u);
-            const int p = __builtin_ctz(gbits | 0x80000000u);  // lowest row attaining the maximum
-            const bool singular = (mx == 0u) || key_not_finite(T(0), mx);
-            if (singular && bad == 0) bad = k + 1;
-            const bool need_swap = (p != k) && !singular;
-            if (__any(need_swap)) {
-                any_swap = true;
-                const int partner = need_swap ? ((i == k) ? p : (i == p) ? k : i) : i;
-                const int from = g * NP + partner;
+#endif
+            // Threshold partial pivoting (same policy as the tile kernels): the diagonal entry is accepted as pivot when
+            // no multiplier of the step exceeds ROWLANE_TAU in magnitude -- always the case for diagonally dominant input,
+            // at the price of one compare. Otherwise (also for a zero / NaN pivot: the multipliers are then Inf / NaN) the
+            // column maximum is searched and brought to row k, i.e. classical partial pivoting for this step.
+            T piv = bcast_lane<NP>(a[k], k);
+            T inv = recip(piv);
+            T negm = (i == k) ? (T)0 : -(a[k] * inv);
+            const bool viol = !(absval(negm) <= (T)ROWLANE_TAU);
+            if (__any(viol)) {
+                // pivot search in column k over rows >= k of this lane's matrix
+                const unsigned key = (i >= k) ? mag_key(a[k]) : 0u;
+                const unsigned mx = group_max<NP>(key);
+                const bool is_max = (key == mx) && (i >= k);
+                const unsigned long long vote = __ballot(is_max);
+                const unsigned gbits = (unsigned)(vote >> (g * NP)) & ((1u << NP) - 1u);
+                const int p = __builtin_ctz(gbits | 0x80000000u);  // lowest row attaining the maximum
+                const bool singular = (mx == 0u) || key_not_finite(T(0), mx);
+                if (singular && bad == 0) bad = k + 1;
+                const bool need_swap = (p != k) && !singular;
+                if (__any(need_swap)) {
+                    any_swap = true;
+                    const int partner = need_swap ? ((i == k) ? p : (i == p) ? k : i) : i;
+                    const int from = g * NP + partner;
 #pragma unroll
-                for (int c = 0; c < NP; ++c) a[c] = __shfl(a[c], from);
-                if (need_swap) src = (src == k) ? p : (src == p) ? k : src;
+                    for (int c = 0; c < NP; ++c) a[c] = __shfl(a[c], from);
+                    // rows >= k have not been pivot rows yet: their rowscale is still 1, nothing else to move
+                    if (need_swap) src = (src == k) ? p : (src == p) ? k : src;
+                }
+                piv = bcast_lane<NP>(a[k], k);
+                inv = recip(piv);
+                negm = (i == k) ? (T)0 : -(a[k] * inv);
             }
-            // 2. normalise + eliminate. m = a[i][k] / pivot (0 on the pivot row, which is scaled instead)
-            const T piv = bcast_lane<NP>(a[k], k);
-            const T inv = recip(piv);
-            const T negm = (i == k) ? (T)0 : -(a[k] * inv);
-            const T scale = (i == k) ? inv : (T)1;
-            elim_step(a, negm, scale, k);
-            a[k] = (i == k) ? inv : negm;
+            // eliminate: a[i][c] -= (a[i][k] / pivot) * a[k][c] for every other row; the pivot row keeps its values
+            elim_step(a, negm, k);
+            a[k] = (i == k) ? (T)1 : negm;
+            rowscale = (i == k) ? inv : rowscale;
         }
+        // the deferred normalisation: row i was the pivot row of exactly one step
+#pragma unroll
+        for (int c = 0; c < NP; ++c) a[c] *= rowscale;
 
         // 3. store; undo the row swaps as a column permutation of the addresses
         const bool fail = bad != 0;
@@ -284,7 +329,14 @@ static hipError_t launch_one(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
     const unsigned gpw = 64 / NP;
     const size_t waves = (batch + gpw - 1) / gpw;
     const size_t blocks = (waves + ROWLANE_THREADS / 64 - 1) / (ROWLANE_THREADS / 64);
-    const unsigned grid = (unsigned)(blocks < 256u * 8u * 2u ? blocks : 256u * 8u * 2u);
+    // persistent-style grid: as many 4-wave blocks as stay resident (one wave per SIMD per block), each wave strides
+    // over the batch; every wave then gets within one iteration of the same work and always has a next matrix to prefetch
+    static const unsigned per_cu = []() {
+        const char *s = getenv("MATINV_ROWLANE_BLOCKS_PER_CU");  // tuning knob for profiling
+        return (unsigned)(s && atoi(s) > 0 ? atoi(s) : 0);
+    }();
+    const unsigned resident = 256u * (per_cu ? per_cu : (unsigned)rowlane_occupancy(sizeof(T), NP, FULL));
+    const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
     hipLaunchKernelGGL((matinv_gj_rowlane<T, NP, FULL>), dim3(grid), dim3(ROWLANE_THREADS), 0, stream, A, X, info, n,
                        (unsigned)batch);
     return hipGetLastError();
