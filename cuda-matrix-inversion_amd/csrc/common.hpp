@@ -14,6 +14,21 @@ struct BatchRef {
     size_t stride;
     T *const *table;  // device-resident pointer table, or nullptr
     __device__ __forceinline__ T *at(size_t k) const { return table ? table[k] : base + k * stride; }
+    // Same for a wave-uniform k: the table entry is moved to SGPRs at once, so that on the (usual) strided path the result
+    // never lives in a VGPR that a pending vector load targets -- otherwise hipcc guards the merge with s_waitcnt vmcnt(0)
+    // on BOTH paths, draining every outstanding load / store / LDS-DMA of the wave at each matrix boundary.
+    __device__ __forceinline__ T *at_uniform(size_t k) const
+    {
+        if (table) {
+            const unsigned long long p = reinterpret_cast<unsigned long long>(table[k]);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+            // rebuilt from integers: say explicitly that it is a global-memory pointer, or every access through it
+            // (and, after the merge, through the strided path too) degrades to flat_load / flat_store
+            typedef __attribute__((address_space(1))) T *global_ptr;
+            return (T *)(global_ptr)(((unsigned long long)hi << 32) | lo);
+        }
+        return base + k * stride;
+    }
 };
 
 template <class T>

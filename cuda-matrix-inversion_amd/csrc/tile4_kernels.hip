@@ -36,8 +36,8 @@ __global__ __launch_bounds__(64 * T4_WAVES, FULL ? 2 : 1) void matinv_gj_tile4_f
     const int w = threadIdx.x >> 6;  // wave-uniform
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
-        const double *A = Ain.at(mat);
-        double *X = Xout.at(mat);
+        const double *A = Ain.at_uniform(mat);
+        double *X = Xout.at_uniform(mat);
         int q = l >> 4, c = l & 15;
         const unsigned lane_off = (unsigned)((l >> 4) * n + (l & 15));
         asm volatile("" : "+v"(q), "+v"(c));  // keep LICM from hoisting ~100 per-lane constants (see tile_kernels.hip)

@@ -40,6 +40,17 @@ struct TileGeo<float> {
     static __device__ __forceinline__ vec4 mfma(float a, float b, vec4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
 
+// LDS ordering inside a ONE-wavefront workgroup: the LDS executes a wave's DS instructions in issue order, so a ds_read
+// after a ds_write needs no counter wait -- only the compiler must keep the order. __syncthreads() would also work but
+// is a workgroup-scope fence: it drains vmcnt, i.e. it would wait for the asynchronous LDS-DMA prefetch of the next
+// matrix (and for the previous matrix's stores) in the middle of the elimination.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 

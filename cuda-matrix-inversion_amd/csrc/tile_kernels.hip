@@ -75,6 +75,8 @@ __device__ __forceinline__ void prep_operands(typename TileGeo<T>::vec4 (&acc)[N
 }
 
 // One matrix per wavefront; see the file header. T = double or float.
+// (Tried and measured, not kept: streaming half of the wave's NEXT matrix into LDS with global_load_lds_dwordx4 during
+// the elimination. The exposed time per matrix is load LATENCY, not bytes: 1.651 ms with, 1.645 ms without at 100 k x 64^2.)
 template <class T, int NT, bool FULL, bool LOOKAHEAD>
 __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
                                              int *work_count, int *work_list, T *panel)
@@ -96,8 +98,8 @@ __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> 
     const int l = threadIdx.x;
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
-        const T *A = Ain.at(mat);
-        T *X = Xout.at(mat);
+        const T *A = Ain.at_uniform(mat);
+        T *X = Xout.at_uniform(mat);
         // Launder the lane coordinates once per matrix: otherwise LICM hoists the ~60 per-lane constants of the 4*NT
         // unrolled block steps (I_4 lanes, e_q entries, lane masks) out of this loop and the allocator spills them.
         int q = l >> 4, c = l & 15;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> 
         if (LOOKAHEAD) {
 #endif
             panel_to_lds<NT, T>(panel, acc, 0, q, c);
-            __syncthreads();
+            wave_lds_sync();
             panel_solve<NT>(panel, 0, q, c, aop, bad);
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
@@ -180,9 +182,9 @@ __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> 
                     };
                     __builtin_amdgcn_sched_barrier(0);
                     issue_b(2);
-                    __syncthreads();  // panel(kb) has been consumed (aop is in registers)
+                    wave_lds_sync();  // panel(kb) has been consumed (aop is in registers)
                     panel_to_lds<NT, T>(panel, acc, kb + 1, q, c);
-                    __syncthreads();
+                    wave_lds_sync();
                     __builtin_amdgcn_sched_barrier(0);
                     T aop_next[NT];
                     PanelSolve<NT, false, T> ps;
@@ -221,9 +223,9 @@ __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> 
 #endif
                 ); ++kb) {
                 panel_to_lds<NT, T>(panel, acc, kb, q, c);
-                __syncthreads();
+                wave_lds_sync();
                 panel_solve<NT>(panel, kb, q, c, aop, bad);
-                __syncthreads();  // panel is rewritten by the next block step
+                wave_lds_sync();  // panel is rewritten by the next block step
                 prep_operands<NT, T>(acc, bop, kb, q, c);
                 // 7. rank-4 update of every tile on the matrix cores
 #pragma unroll
@@ -269,7 +271,7 @@ __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> 
             const int slot = atomicAdd(work_count, 1);
             work_list[slot] = (int)mat;
         }
-        if (LOOKAHEAD) __syncthreads();  // the next matrix's first panel write must not pass this one's last reads
+        if (LOOKAHEAD) wave_lds_sync();  // the next matrix's first panel write must not pass this one's last reads
     }
 }
 
@@ -328,8 +330,8 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
     const int l = threadIdx.x;
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
-        const double *A = Ain.at(mat);
-        double *X = Xout.at(mat);
+        const double *A = Ain.at_uniform(mat);
+        double *X = Xout.at_uniform(mat);
         int q = l >> 4, c = l & 15;
         const unsigned lane_off = (unsigned)((l >> 4) * n + (l & 15));
         asm volatile("" : "+v"(q), "+v"(c));  // see matinv_gj_tile_f64
