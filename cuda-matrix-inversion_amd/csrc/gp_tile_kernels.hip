@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
         unsigned long long bad = 0;
         double aop[NX], bop[NX];
         spd_panel_to_lds<NX>(panel, acc, 0, q, c);
-        __syncthreads();
+        wave_lds_sync();
         {
             PanelSolve<NX, true> ps0;
 #pragma unroll
@@ -103,9 +103,9 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
                         if (e == ev && (flush || thr <= count)) {
                             __builtin_amdgcn_sched_barrier(0);
                             if (e == 0) {
-                                __syncthreads();
+                                wave_lds_sync();
                                 spd_panel_to_lds<NX>(panel, acc, kb + 1, q, c);
-                                __syncthreads();
+                                wave_lds_sync();
                             } else if (e - 1 < 6 || e - 1 - 6 >= tn) {  // tile rows above the next pivot block are dead
                                 ps.stage(e - 1, panel, kb + 1, q, c, aop_next, bop_next, bad);
                             }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
             const int slot = atomicAdd(work_count, 1);
             work_list[slot] = (int)mat;
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
         double aop[NT], bop[NT];
 
         spd_panel_to_lds<NT>(panel, acc, 0, q, c);
-        __syncthreads();
+        wave_lds_sync();
         {
             PanelSolve<NT, true> ps0;
 #pragma unroll
@@ -406,9 +406,9 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
                         if (e == ev && (flush || thr <= count)) {
                             __builtin_amdgcn_sched_barrier(0);
                             if (e == 0) {
-                                __syncthreads();
+                                wave_lds_sync();
                                 spd_panel_to_lds<NT>(panel, acc, kb + 1, q, c);
-                                __syncthreads();
+                                wave_lds_sync();
                             } else {
                                 ps.stage(e - 1, panel, kb + 1, q, c, aop_next, bop_next, bad);
                             }
@@ -456,10 +456,10 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
                         if (FULL || (row < n && col < n)) X[(unsigned)(row * n + col)] = -acc[ti][tj][r];
                     }
                     if (tj < ti) {
-                        __syncthreads();
+                        wave_lds_sync();
 #pragma unroll
                         for (int r = 0; r < 4; ++r) panel[(4 * r + q) * TSTRIDE + c] = -acc[ti][tj][r];
-                        __syncthreads();
+                        wave_lds_sync();
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             // element (row 16tj + 4r + q, col 16ti + c) of the result = tile(ti,tj)[c][4r + q]
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
             const int slot = atomicAdd(work_count, 1);
             work_list[slot] = (int)mat;
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
