@@ -8,5 +8,5 @@ Package layout (only what the hot path needs):
   shard.py   batch partitioning across GPUs and result reassembly (RCCL all-gather)
 """
 from . import mats  # noqa: F401
-from ._lib import (ALGO_CHOLESKY, ALGO_GAUSS_JORDAN, F32, F64, KERNEL_AUTO, KERNEL_LDS, KERNEL_ROWLANE,  # noqa: F401
-                   KERNEL_TILE, MatinvError, build)
+from ._lib import (ALGO_CHOLESKY, ALGO_GAUSS_JORDAN, F32, F64, KERNEL_AUTO, KERNEL_LDS, KERNEL_ROW,  # noqa: F401
+                   KERNEL_ROWLANE, KERNEL_TILE, MatinvError, build)

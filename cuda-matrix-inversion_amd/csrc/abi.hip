@@ -106,6 +106,11 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
             return fail(MATINV_ERR_UNSUPPORTED, "tile family serves f64 Gauss-Jordan with n <= 128 only (n=%d)", n);
         e = launch_gj_tile<T>(n, A, X, batch, dInfo, stream);
         break;
+    case MATINV_KERNEL_ROW:
+        if (algo != MATINV_ALGO_GAUSS_JORDAN || !row_family_supports<T>(n))
+            return fail(MATINV_ERR_UNSUPPORTED, "row family serves Gauss-Jordan with n <= 64 only (n=%d)", n);
+        e = launch_gj_row<T>(n, A, X, batch, dInfo, stream);
+        break;
     default:
         return fail(MATINV_ERR_ARG, "unknown kernel family %d", kernel);
     }
@@ -380,6 +385,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     case MATINV_KERNEL_LDS: return algo == MATINV_ALGO_CHOLESKY ? name_chol_lds(f64) : name_gj_lds(f64);
     case MATINV_KERNEL_ROWLANE: return name_gj_rowlane(f64, n);
     case MATINV_KERNEL_TILE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_tile(f64, n) : name_gj_tile(f64, n);
+    case MATINV_KERNEL_ROW: return name_gj_row(f64, n);
     default: return "";
     }
 }

@@ -65,6 +65,16 @@ hipError_t launch_gj_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
 template <class T>
 bool rowlane_family_supports(int n);
 
+// ROW family (row_kernels.hip): true partial pivoting, one matrix per wavefront, n <= 64
+template <class T>
+bool row_family_supports(int n);
+template <class T>
+hipError_t launch_gj_row(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+hipError_t launch_gj_row_worklist(int n, BatchRef<const T> A, BatchRef<T> X, const int *work_count, const int *work_list,
+                                  int *info, hipStream_t stream);
+const char *name_gj_row(bool f64, int n);
+
 template <class T>
 hipError_t launch_gj_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 template <class T>

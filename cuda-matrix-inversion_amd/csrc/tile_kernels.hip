@@ -26,8 +26,8 @@
 // Pivoting: this fast path eliminates in natural order and VERIFIES instead of searching: every multiplier it
 // forms (the 6 LU multipliers of each 4x4 pivot block and every entry of Aop outside the pivot rows) must be
 // <= TAU in magnitude (threshold pivoting acceptance; scale invariant; NaN/Inf fail it). A matrix that fails is
-// appended to a device work list and redone, in the same stream, by the partially pivoted LDS kernel
-// (lds_kernels.hip) -- no host round trip. Diagonally dominant / SPD batches (the reference's fixtures,
+// appended to a device work list and redone, in the same stream, by the partially pivoted ROW kernel
+// (row_kernels.hip; the LDS kernel for n > 64) -- no host round trip. Diagonally dominant / SPD batches (the reference's fixtures,
 // tests/generate_inverse_matrices.m:12-18) never take the fallback.
 //
 // Replaces the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95.
@@ -516,7 +516,7 @@ hipError_t launch_gj_tile<float>(int n, BatchRef<const float> A, BatchRef<float>
     }
 #undef TILE_LAUNCH_F32
     e = hipGetLastError();
-    if (e == hipSuccess) e = launch_gj_lds_worklist<float>(n, A, X, ws, ws + 1, info, stream);
+    if (e == hipSuccess) e = launch_gj_row_worklist<float>(n, A, X, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
 }
@@ -557,7 +557,7 @@ hipError_t launch_gj_tile<double>(int n, BatchRef<const double> A, BatchRef<doub
     }
 #undef TILE_LAUNCH
     e = hipGetLastError();
-    if (e == hipSuccess) e = launch_gj_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream);
+    if (e == hipSuccess) e = launch_gj_row_worklist<double>(n, A, X, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
 }

@@ -54,7 +54,9 @@ typedef enum {
     MATINV_KERNEL_ROWLANE = 2, /* n <= 16: 64/npad matrices per wavefront, one row per lane, DPP broadcasts     */
     MATINV_KERNEL_TILE = 3     /* 16x16 MFMA accumulator tiles: blocked Gauss-Jordan with one wavefront per matrix (n <= 64,
                                   f64 and f32) or four (64 < n <= 128, f64); for MATINV_ALGO_CHOLESKY the symmetric blocked
-                                  sweep on lower-triangular tiles (n <= 64, f64) */
+                                  sweep on lower-triangular tiles (n <= 64, f64) */,
+    MATINV_KERNEL_ROW = 4      /* n <= 64: one matrix per wavefront, row per lane, classical partial pivoting with the pivot
+                                  row broadcast through v_readlane; the pivoting path behind the tile family */
 } matinv_kernel;
 
 /* Invert `batch` matrices that are already resident in device memory.

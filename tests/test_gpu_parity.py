@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 api = pkg("api")
 GJ, CH = api.ALGO_GAUSS_JORDAN, api.ALGO_CHOLESKY
-FAMILIES = {"auto": api.KERNEL_AUTO, "lds": api.KERNEL_LDS, "rowlane": api.KERNEL_ROWLANE, "tile": api.KERNEL_TILE}
+FAMILIES = {"auto": api.KERNEL_AUTO, "lds": api.KERNEL_LDS, "rowlane": api.KERNEL_ROWLANE, "tile": api.KERNEL_TILE,
+            "row": api.KERNEL_ROW}
 
 
 def dev(x):
