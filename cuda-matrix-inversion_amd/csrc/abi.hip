@@ -62,6 +62,7 @@ int select_auto(int algo, int n)
         return MATINV_KERNEL_TILE;
     }
     if (lds_family_supports<T>(n)) return MATINV_KERNEL_LDS;
+    if (global_family_supports<T>(n)) return MATINV_KERNEL_GLOBAL;
     return MATINV_ERR_UNSUPPORTED;
 }
 
@@ -81,7 +82,7 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
         kernel = (algo == MATINV_ALGO_CHOLESKY && chol_phases != 7 && lds_family_supports<T>(n)) ? (int)MATINV_KERNEL_LDS
                                                                                                  : select_auto<T>(algo, n);
         if (kernel < 0)
-            return fail(MATINV_ERR_UNSUPPORTED, "n=%d exceeds every kernel family built in (LDS family limit)", n);
+            return fail(MATINV_ERR_UNSUPPORTED, "n=%d exceeds every kernel family built in (limit 1024)", n);
     }
     hipError_t e = hipErrorInvalidValue;
     switch (kernel) {
@@ -105,6 +106,12 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
         if (!tile_family_supports<T>(n))
             return fail(MATINV_ERR_UNSUPPORTED, "tile family serves f64 Gauss-Jordan with n <= 128 only (n=%d)", n);
         e = launch_gj_tile<T>(n, A, X, batch, dInfo, stream);
+        break;
+    case MATINV_KERNEL_GLOBAL:
+        if (!global_family_supports<T>(n) || chol_phases != 7)
+            return fail(MATINV_ERR_UNSUPPORTED, "global family serves full inversions with n <= 1024 only (n=%d)", n);
+        e = (algo == MATINV_ALGO_GAUSS_JORDAN) ? launch_gj_global<T>(n, A, X, batch, dInfo, stream)
+                                               : launch_chol_global<T>(n, A, X, batch, dInfo, stream);
         break;
     case MATINV_KERNEL_ROW:
         if (algo != MATINV_ALGO_GAUSS_JORDAN || !row_family_supports<T>(n))
@@ -277,7 +284,15 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             return MATINV_OK;
         }
     }
-    if (!lds_family_supports<T>(n)) return fail(MATINV_ERR_UNSUPPORTED, "pipeline: n=%d does not fit 160 KiB of LDS", n);
+    if (!lds_family_supports<T>(n)) {
+        if (!global_family_supports<T>(n)) return fail(MATINV_ERR_UNSUPPORTED, "pipeline: n=%d exceeds the limit 1024", n);
+        hipError_t eg = launch_gp_global<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
+                                            static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
+                                            static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,
+                                            static_cast<hipStream_t>(stream));
+        if (eg != hipSuccess) return fail_hip(eg, "kernel launch");
+        return MATINV_OK;
+    }
     hipError_t e = launch_gp_lds<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
                                     variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
                                     static_cast<T *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
@@ -386,6 +401,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     case MATINV_KERNEL_ROWLANE: return name_gj_rowlane(f64, n);
     case MATINV_KERNEL_TILE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_tile(f64, n) : name_gj_tile(f64, n);
     case MATINV_KERNEL_ROW: return name_gj_row(f64, n);
+    case MATINV_KERNEL_GLOBAL: return algo == MATINV_ALGO_CHOLESKY ? name_chol_global(f64) : name_gj_global(f64);
     default: return "";
     }
 }

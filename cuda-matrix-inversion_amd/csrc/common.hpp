@@ -65,6 +65,19 @@ hipError_t launch_gj_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
 template <class T>
 bool rowlane_family_supports(int n);
 
+// GLOBAL family (global_kernels.hip): any n <= 1024, working copy in global memory
+template <class T>
+bool global_family_supports(int n);
+template <class T>
+hipError_t launch_gj_global(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+hipError_t launch_chol_global(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+hipError_t launch_gp_global(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                            int *info, hipStream_t stream);
+const char *name_gj_global(bool f64);
+const char *name_chol_global(bool f64);
+
 // ROW family (row_kernels.hip): true partial pivoting, one matrix per wavefront, n <= 64
 template <class T>
 bool row_family_supports(int n);

@@ -26,7 +26,7 @@ extern "C" {
 typedef enum {
     MATINV_OK = 0,
     MATINV_ERR_ARG = -1,         /* bad n / batch / pointer / stride                   */
-    MATINV_ERR_UNSUPPORTED = -2, /* n too large for every kernel family built in       */
+    MATINV_ERR_UNSUPPORTED = -2, /* n > 1024, or the forced kernel family cannot serve it */
     MATINV_ERR_HIP = -3,         /* a HIP runtime call failed (message in last_error)  */
     MATINV_ERR_NO_DEVICE = -4    /* no gfx950 device visible                           */
 } matinv_status;
@@ -55,8 +55,10 @@ typedef enum {
     MATINV_KERNEL_TILE = 3     /* 16x16 MFMA accumulator tiles: blocked Gauss-Jordan with one wavefront per matrix (n <= 64,
                                   f64 and f32) or four (64 < n <= 128, f64); for MATINV_ALGO_CHOLESKY the symmetric blocked
                                   sweep on lower-triangular tiles (n <= 64, f64) */,
-    MATINV_KERNEL_ROW = 4      /* n <= 64: one matrix per wavefront, row per lane, classical partial pivoting with the pivot
+    MATINV_KERNEL_ROW = 4,     /* n <= 64: one matrix per wavefront, row per lane, classical partial pivoting with the pivot
                                   row broadcast through v_readlane; the pivoting path behind the tile family */
+    MATINV_KERNEL_GLOBAL = 5   /* any n <= 1024 (the reference's limit): one 1024-thread workgroup per matrix, working copy
+                                  in global memory; the functional path for matrices that do not fit on chip */
 } matinv_kernel;
 
 /* Invert `batch` matrices that are already resident in device memory.

@@ -44,6 +44,8 @@ def test_kernel_selection_is_pure_host_logic():
         assert k in (api.KERNEL_LDS, api.KERNEL_ROWLANE, api.KERNEL_TILE)
         assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, n).startswith("matinv_")
         assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, n) == (api.KERNEL_TILE if n <= 64 else api.KERNEL_LDS)
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 512) == api.KERNEL_GLOBAL
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 150) == api.KERNEL_LDS
     with pytest.raises(pkg("_lib").MatinvError):
         api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 4096)
 

@@ -182,6 +182,49 @@ def test_singular_and_not_spd_report_info(n):
     assert np.isnan(as_mats(got, n)[1]).all()
 
 
+@pytest.mark.parametrize("n,batch", [(142, 5), (200, 4), (257, 3), (512, 2), (1024, 1)])
+def test_large_n_global_family(n, batch):
+    """Sizes that no longer fit on chip (the reference accepts n <= 1024: one thread per row, batched_invert.cu:87-93)."""
+    a = spd_batch(n, batch, seed=n)
+    want, _ = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT)
+    got, info = gpu_inverse(a, n, GJ, want_info=True)
+    assert not info.any() and rel_err(got, want, n) < 1e-10
+    gotc, info = gpu_inverse(a, n, CH, want_info=True)
+    assert not info.any() and rel_err(gotc, want, n) < 1e-10
+    if n <= 512:
+        g = general_batch(n, 2, seed=7 * n)
+        wg, _ = oracle.inverse_batched(g, n, oracle.ALGO_GJ_PIVOT)
+        cond = max(np.linalg.cond(m) for m in as_mats(g, n))
+        assert rel_err(gpu_inverse(g, n, GJ), wg, n) < max(1e-10, 1e-15 * cond * n)
+        rng = np.random.default_rng(n)
+        va, vc, vd = (rng.random(batch * n) for _ in range(3))
+        ve = rng.random(batch)
+        t = [dev(x) for x in (va, a, vc, vd, ve)]
+        m = api.calcluateMean(n, t[0], t[1], t[2], t[3]).cpu().numpy()
+        v = api.calcluateVariance(n, t[0], t[1], t[2], t[4]).cpu().numpy()
+        assert np.abs(m - oracle.mean_batched(va, a, vc, vd, n)).max() < 1e-10
+        assert np.abs(v - oracle.variance_batched(va, a, vc, ve, n)).max() < 1e-10
+    with pytest.raises(pkg("_lib").MatinvError):
+        api.inverse_batched(torch.zeros(4, dtype=torch.float64, device="cuda"), 1025, GJ, batch=0 + 1)
+
+
+def test_large_n_singular_and_fp32():
+    n = 160
+    a = spd_batch(n, 3, seed=1).reshape(3, n, n)
+    a[1, 5, :] = 0.0
+    got, info = gpu_inverse(a.reshape(-1), n, GJ, want_info=True)
+    assert info.tolist() == [0, 6, 0] and np.isnan(as_mats(got, n)[1]).all()
+    b = spd_batch(n, 2, seed=2)
+    want, _ = oracle.inverse_batched(b, n, oracle.ALGO_GJ_PIVOT)
+    n32 = 256
+    c = spd_batch(n32, 2, seed=3)
+    want32, _ = oracle.inverse_batched(c, n32, oracle.ALGO_GJ_PIVOT)
+    got32 = gpu_inverse(c.astype(np.float32), n32, GJ).astype(np.float64)
+    x, y = got32.reshape(-1, n32 * n32), want32.reshape(-1, n32 * n32)
+    assert (np.linalg.norm(x - y, axis=1) / np.linalg.norm(y, axis=1)).max() < 1e-4
+    assert rel_err(gpu_inverse(b, n, GJ), want, n) < 1e-10
+
+
 def test_empty_and_single_batch():
     e = torch.empty(0, dtype=torch.float64, device="cuda")
     out = api.inverse_batched(e, 8, GJ, batch=0)
