@@ -225,6 +225,30 @@ def test_large_n_singular_and_fp32():
     assert rel_err(gpu_inverse(b, n, GJ), want, n) < 1e-10
 
 
+def test_randomized_sizes_batches_dtypes():
+    """Seeded sweep over odd sizes / batch counts (ragged last wavefront, identity padding, every dispatch boundary):
+    n in 1..140, batch in 1..260, both precisions, both algorithms, SPD and general inputs."""
+    rng = np.random.default_rng(20261003)
+    for trial in range(60):
+        n = int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 23, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 80, 97, 127, 128, 129, 140]))
+        batch = int(rng.integers(1, 261)) if n <= 64 else int(rng.integers(1, 12))
+        f32 = bool(rng.integers(0, 2))
+        general = bool(rng.integers(0, 3) == 0) and n <= 64
+        algo = GJ if (general or rng.integers(0, 2)) else CH
+        a = general_batch(n, batch, seed=trial) if general else spd_batch(n, batch, seed=trial)
+        want, oinfo = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT if algo == GJ else oracle.ALGO_CHOLESKY)
+        assert not oinfo.any()
+        got, info = gpu_inverse(a.astype(np.float32) if f32 else a, n, algo, want_info=True)
+        assert not info.any(), (trial, n, batch, f32, general, algo)
+        cond = max(np.linalg.cond(m) for m in as_mats(a, n)[: min(batch, 8)]) if general else 3.0
+        if f32:
+            x, y = got.astype(np.float64).reshape(-1, n * n), want.reshape(-1, n * n)
+            fro = np.linalg.norm(x - y, axis=1) / np.linalg.norm(y, axis=1)
+            assert fro.max() < 2e-5 * max(cond, 10.0), (trial, n, batch, general, algo, fro.max())
+        else:
+            assert rel_err(got, want, n) < max(1e-10, 1e-14 * cond * n), (trial, n, batch, general, algo)
+
+
 def test_empty_and_single_batch():
     e = torch.empty(0, dtype=torch.float64, device="cuda")
     out = api.inverse_batched(e, 8, GJ, batch=0)
