@@ -269,17 +269,16 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
     if (batch > 0x7fffffffu) return fail(MATINV_ERR_ARG, "batch %zu exceeds the grid limit; split the call", batch);
     int rc = check_device();
     if (rc) return rc;
-    if constexpr (sizeof(T) == 8) {
+    {
         static const bool use_tile = []() {
             const char *s = getenv("MATINV_GP_TILE");  // A/B switch for profiling; default on
             return !(s && *s == '0');
         }();
-        if (use_tile && gp_tile_supports_f64(n)) {
-            hipError_t e = launch_gp_tile_f64(n, static_cast<const double *>(a), static_cast<const double *>(B),
-                                              static_cast<const double *>(c),
-                                              variance ? nullptr : static_cast<const double *>(d),
-                                              static_cast<const double *>(e_), static_cast<double *>(out), batch, dInfo,
-                                              static_cast<hipStream_t>(stream));
+        if (use_tile && gp_tile_supports(n)) {
+            hipError_t e = launch_gp_tile<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
+                                             static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
+                                             static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,
+                                             static_cast<hipStream_t>(stream));
             if (e != hipSuccess) return fail_hip(e, "kernel launch");
             return MATINV_OK;
         }

@@ -109,11 +109,12 @@ const char *name_gj_tile(bool f64, int n);
 template <class T>
 hipError_t launch_gp_lds_worklist(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out,
                                   const int *work_count, const int *work_list, int *info, hipStream_t stream);
-// fused GP scalars on the MFMA tile layout, f64, n <= 64 (gp_tile_kernels.hip)
-bool gp_tile_supports_f64(int n);
-hipError_t launch_gp_tile_f64(int n, const double *As, const double *Bs, const double *Cs, const double *Ds,
-                              const double *Es, double *out, size_t batch, int *info, hipStream_t stream);
-const char *name_gp_tile_f64(int n);
+// fused GP scalars on the MFMA tile layout, n <= 64, f64 and f32 (gp_tile_kernels.hip)
+bool gp_tile_supports(int n);
+template <class T>
+hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                          int *info, hipStream_t stream);
+const char *name_gp_tile(bool f64, int n);
 const char *name_gj_lds(bool f64);
 const char *name_chol_lds(bool f64);
 const char *name_gp_lds(bool f64);

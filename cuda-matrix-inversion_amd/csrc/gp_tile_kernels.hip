@@ -14,29 +14,29 @@
 
 namespace matinv {
 
-template <int NT, bool FULL>
-__global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, const double *Bs, const double *Cs,
-                                                           const double *Ds, const double *Es, double *out, int *info,
-                                                           int n_rt, unsigned batch, int *work_count, int *work_list)
+template <class T, int NT, bool FULL>
+__device__ __forceinline__ void gp_tile_body(const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out,
+                                             int *info, int n_rt, unsigned batch, int *work_count, int *work_list, T *panel)
 {
+    typedef TileGeo<T> G;
+    typedef typename G::vec4 vec4;
     constexpr int N = 16 * NT;
     constexpr int NX = NT + 1;  // tile rows/cols of the bordered matrix; R = NT is the border
     constexpr int R = NT;
     constexpr int NKB = 4 * NT;
     const int n = FULL ? N : n_rt;
     const bool variance = (Ds == nullptr);
-    __shared__ __attribute__((aligned(16))) double panel[(N + 16) * 4];
     const int l = threadIdx.x;
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
-        const double *B = Bs + (size_t)mat * n * n;
-        const double *va = As + (size_t)mat * n;
-        const double *vw = variance ? va : Ds + (size_t)mat * n;
-        const double *vc = Cs + (size_t)mat * n;
+        const T *B = Bs + (size_t)mat * n * n;
+        const T *va = As + (size_t)mat * n;
+        const T *vw = variance ? va : Ds + (size_t)mat * n;
+        const T *vc = Cs + (size_t)mat * n;
         int q = l >> 4, c = l & 15;
         asm volatile("" : "+v"(q), "+v"(c));  // see matinv_gj_tile_f64
 
-        v4d acc[NX][NX];
+        vec4 acc[NX][NX];
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -44,11 +44,11 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
                 if (tj > ti) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                    const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
                     const bool in = FULL || (row < n && col < n);
                     const int hi = row > col ? row : col, lo = row > col ? col : row;
                     // only the lower triangle of B is read (mirror position inside the diagonal tiles)
-                    double v = in ? B[(unsigned)(lo * n + hi)] : ((row == col) ? 1.0 : 0.0);
+                    T v = in ? B[(unsigned)(lo * n + hi)] : ((row == col) ? (T)1 : (T)0);
                     if (ti == tj && row == col && in) v += vc[row];  // addDiagonal, gauss_bench.cu:38-43
                     acc[ti][tj][r] = v;
                 }
@@ -57,43 +57,43 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
         for (int tj = 0; tj < NT; ++tj) {
             const int col = 16 * tj + c;
             const bool in = FULL || col < n;
-            const double u = in ? va[col] : 0.0, w = in ? vw[col] : 0.0;
-            acc[R][tj][0] = (q == 0) ? u : (q == 1) ? w : 0.0;  // border rows 0 (a) and 1 (d); rows 2..15 are zero
-            acc[R][tj][1] = 0.0, acc[R][tj][2] = 0.0, acc[R][tj][3] = 0.0;
+            const T u = in ? va[col] : (T)0, w = in ? vw[col] : (T)0;
+            acc[R][tj][0] = (q == 0) ? u : (q == 1) ? w : (T)0;  // border rows trow(0,0) (a) and trow(0,1) (d); the others are zero
+            acc[R][tj][1] = (T)0, acc[R][tj][2] = (T)0, acc[R][tj][3] = (T)0;
         }
-        acc[R][R] = v4d{0.0, 0.0, 0.0, 0.0};
+        acc[R][R] = vec4{(T)0, (T)0, (T)0, (T)0};
 
         unsigned long long bad = 0;
-        double aop[NX], bop[NX];
-        spd_panel_to_lds<NX>(panel, acc, 0, q, c);
+        T aop[NX], bop[NX];
+        spd_panel_to_lds<NX, T>(panel, acc, 0, q, c);
         wave_lds_sync();
         {
-            PanelSolve<NX, true> ps0;
+            PanelSolve<NX, true, T> ps0;
 #pragma unroll
-            for (int s = 0; s < PanelSolve<NX, true>::NSTAGE; ++s) ps0.stage(s, panel, 0, q, c, aop, bop, bad);
+            for (int s = 0; s < PanelSolve<NX, true, T>::NSTAGE; ++s) ps0.stage(s, panel, 0, q, c, aop, bop, bad);
         }
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const int tK = kb >> 2;
-            spd_prep_operands<NX>(acc, bop, kb, q, c);
+            spd_prep_operands<NX, T>(acc, bop, kb, q, c);
             if (kb + 1 < NKB) {
                 const int tn = (kb + 1) >> 2;
                 // (a) the tile column the next panel is read from (rows above it are dead)
 #pragma unroll
                 for (int ti = 0; ti < NX; ++ti) {
                     if (ti < tn) continue;
-                    acc[ti][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tn], acc[ti][tn], 0, 0, 0);
+                    acc[ti][tn] = G::mfma(aop[ti], bop[tn], acc[ti][tn]);
                 }
                 // (b) the other LIVE lower tiles (tile column >= tK), pinned between the pieces of the next panel
-                constexpr int NS = PanelSolve<NX, true>::NSTAGE;
+                constexpr int NS = PanelSolve<NX, true, T>::NSTAGE;
                 int nb = 0;  // number of (b) tiles: folds to a literal
 #pragma unroll
                 for (int ti = 0; ti < NX; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < NX; ++tj)
                         if (tj <= ti && tj >= tK && tj != tn) ++nb;
-                double aop_next[NX], bop_next[NX];
-                PanelSolve<NX, true> ps;
+                T aop_next[NX], bop_next[NX];
+                PanelSolve<NX, true, T> ps;
                 int count = 0, ev = 0;
                 auto run_events = [&](bool flush) {
 #pragma unroll
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
                             __builtin_amdgcn_sched_barrier(0);
                             if (e == 0) {
                                 wave_lds_sync();
-                                spd_panel_to_lds<NX>(panel, acc, kb + 1, q, c);
+                                spd_panel_to_lds<NX, T>(panel, acc, kb + 1, q, c);
                                 wave_lds_sync();
                             } else if (e - 1 < 6 || e - 1 - 6 >= tn) {  // tile rows above the next pivot block are dead
                                 ps.stage(e - 1, panel, kb + 1, q, c, aop_next, bop_next, bad);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
 #pragma unroll
                     for (int tj = 0; tj < NX; ++tj) {
                         if (tj > ti || tj < tK || tj == tn) continue;
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc[ti][tj], 0, 0, 0);
+                        acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
                         ++count;
                         run_events(false);
                     }
@@ -129,17 +129,18 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
                 for (int ti = 0; ti < NX; ++ti) { aop[ti] = aop_next[ti]; bop[ti] = bop_next[ti]; }
             } else {
                 // last pivot block: only the corner matters
-                acc[R][R] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[R], bop[R], acc[R][R], 0, 0, 0);
+                acc[R][R] = G::mfma(aop[R], bop[R], acc[R][R]);
             }
         }
 
         if (bad == 0) {
-            // corner tile G = -V^T M^-1 V: G[0][0] at lane (q=0, c=0), G[0][1] at lane (q=0, c=1), register 0
-            const double g = acc[R][R][0];
+            // corner tile G = -V^T M^-1 V, register 0, lane group q = 0 (row of a): G[a][a] at column trow(0,0) = lane 0,
+            // G[a][d] at column trow(0,1)
+            const T g = acc[R][R][0];
             if (variance) {
                 if (l == 0) out[mat] = Es[mat] + g;
             } else {
-                if (l == 1) out[mat] = -g;
+                if (l == G::trow(0, 1)) out[mat] = -g;
             }
             if (info && l == 0) info[mat] = 0;
         } else if (l == 0) {
@@ -150,12 +151,32 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
     }
 }
 
-bool gp_tile_supports_f64(int n) { return n >= 1 && n <= 64; }
 
-hipError_t launch_gp_tile_f64(int n, const double *As, const double *Bs, const double *Cs, const double *Ds,
-                              const double *Es, double *out, size_t batch, int *info, hipStream_t stream)
+template <int NT, bool FULL>
+__global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, const double *Bs, const double *Cs,
+                                                           const double *Ds, const double *Es, double *out, int *info,
+                                                           int n_rt, unsigned batch, int *work_count, int *work_list)
 {
-    if (!gp_tile_supports_f64(n)) return hipErrorInvalidValue;
+    __shared__ __attribute__((aligned(16))) double panel[(16 * NT + 16) * 4];
+    gp_tile_body<double, NT, FULL>(As, Bs, Cs, Ds, Es, out, info, n_rt, batch, work_count, work_list, panel);
+}
+
+template <int NT, bool FULL>
+__global__ __launch_bounds__(64, 3) void matinv_gp_tile_f32(const float *As, const float *Bs, const float *Cs,
+                                                           const float *Ds, const float *Es, float *out, int *info,
+                                                           int n_rt, unsigned batch, int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) float panel[(16 * NT + 16) * 4];
+    gp_tile_body<float, NT, FULL>(As, Bs, Cs, Ds, Es, out, info, n_rt, batch, work_count, work_list, panel);
+}
+
+bool gp_tile_supports(int n) { return n >= 1 && n <= 64; }
+
+template <class T>
+hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                          int *info, hipStream_t stream)
+{
+    if (!gp_tile_supports(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -166,32 +187,44 @@ hipError_t launch_gp_tile_f64(int n, const double *As, const double *Bs, const d
     const unsigned grid = (unsigned)(batch < 256u * 8u * 4u ? batch : 256u * 8u * 4u);
     const unsigned b = (unsigned)batch;
 #define GP_LAUNCH(NT_)                                                                                                \
-    if (n == 16 * NT_)                                                                                                \
-        hipLaunchKernelGGL((matinv_gp_tile_f64<NT_, true>), dim3(grid), dim3(64), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
-    else                                                                                                              \
-        hipLaunchKernelGGL((matinv_gp_tile_f64<NT_, false>), dim3(grid), dim3(64), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1)
+    if constexpr (sizeof(T) == 8) {                                                                                   \
+        if (n == 16 * NT_)                                                                                            \
+            hipLaunchKernelGGL((matinv_gp_tile_f64<NT_, true>), dim3(grid), dim3(64), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((matinv_gp_tile_f64<NT_, false>), dim3(grid), dim3(64), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
+    } else {                                                                                                          \
+        if (n == 16 * NT_)                                                                                            \
+            hipLaunchKernelGGL((matinv_gp_tile_f32<NT_, true>), dim3(grid), dim3(64), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((matinv_gp_tile_f32<NT_, false>), dim3(grid), dim3(64), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
+    }
     switch (nt) {
-    case 1: GP_LAUNCH(1); break;
-    case 2: GP_LAUNCH(2); break;
-    case 3: GP_LAUNCH(3); break;
-    default: GP_LAUNCH(4); break;
+    case 1: GP_LAUNCH(1) break;
+    case 2: GP_LAUNCH(2) break;
+    case 3: GP_LAUNCH(3) break;
+    default: GP_LAUNCH(4) break;
     }
 #undef GP_LAUNCH
     e = hipGetLastError();
-    if (e == hipSuccess) e = launch_gp_lds_worklist<double>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
+    if (e == hipSuccess) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
 }
+template hipError_t launch_gp_tile<double>(int, const double *, const double *, const double *, const double *,
+                                           const double *, double *, size_t, int *, hipStream_t);
+template hipError_t launch_gp_tile<float>(int, const float *, const float *, const float *, const float *, const float *,
+                                          float *, size_t, int *, hipStream_t);
 
-const char *name_gp_tile_f64(int n)
+const char *name_gp_tile(bool f64, int n)
 {
     const bool full = (n % 16) == 0;
-    switch ((n + 15) / 16) {
-    case 1: return full ? "matinv_gp_tile_f64<1, true>" : "matinv_gp_tile_f64<1, false>";
-    case 2: return full ? "matinv_gp_tile_f64<2, true>" : "matinv_gp_tile_f64<2, false>";
-    case 3: return full ? "matinv_gp_tile_f64<3, true>" : "matinv_gp_tile_f64<3, false>";
-    default: return full ? "matinv_gp_tile_f64<4, true>" : "matinv_gp_tile_f64<4, false>";
-    }
+    const int nt = (n + 15) / 16;
+    static const char *names[2][2][4] = {
+        {{"matinv_gp_tile_f32<1, false>", "matinv_gp_tile_f32<2, false>", "matinv_gp_tile_f32<3, false>", "matinv_gp_tile_f32<4, false>"},
+         {"matinv_gp_tile_f32<1, true>", "matinv_gp_tile_f32<2, true>", "matinv_gp_tile_f32<3, true>", "matinv_gp_tile_f32<4, true>"}},
+        {{"matinv_gp_tile_f64<1, false>", "matinv_gp_tile_f64<2, false>", "matinv_gp_tile_f64<3, false>", "matinv_gp_tile_f64<4, false>"},
+         {"matinv_gp_tile_f64<1, true>", "matinv_gp_tile_f64<2, true>", "matinv_gp_tile_f64<3, true>", "matinv_gp_tile_f64<4, true>"}}};
+    return names[f64 ? 1 : 0][full ? 1 : 0][(nt < 1 ? 1 : nt > 4 ? 4 : nt) - 1];
 }
 
 }  // namespace matinv

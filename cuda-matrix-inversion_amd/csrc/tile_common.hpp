@@ -203,42 +203,44 @@ __device__ __forceinline__ void panel_solve(const T *panel, int kb, int q, int c
 }
 
 // ---- symmetric (lower-triangular tile storage) helpers, shared by the SPD inverse and the fused GP kernel ----------
-template <int NT>
-__device__ __forceinline__ void spd_panel_to_lds(double *panel, const v4d (&acc)[NT][NT], int kb, int q, int c)
+template <int NT, class T>
+__device__ __forceinline__ void spd_panel_to_lds(T *panel, const typename TileGeo<T>::vec4 (&acc)[NT][NT], int kb, int q, int c)
 {
-    const int tK = kb >> 2, rK = kb & 3, c0 = 4 * (kb & 3);
-    if (c >= c0 && c < c0 + 4) {
+    typedef TileGeo<T> G;
+    const int tK = kb >> 2, rK = kb & 3;
+    if (G::blk(c) == rK) {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             if (ti < tK) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) panel[(16 * ti + 4 * r + q) * 4 + (c - c0)] = acc[ti][tK][r];
+            for (int r = 0; r < 4; ++r) panel[(16 * ti + G::trow(r, q)) * 4 + G::piv(c)] = acc[ti][tK][r];
         }
     }
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         if (ti >= tK) continue;
-        panel[(16 * ti + c) * 4 + q] = acc[tK][ti][rK];  // W[16ti + c][K0 + q] = W[K0 + q][16ti + c]
+        panel[(16 * ti + c) * 4 + q] = acc[tK][ti][rK];  // W[16ti + c][pivot q] = W[pivot q][16ti + c]
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void spd_prep_operands(v4d (&acc)[NT][NT], double (&bop)[NT], int kb, int q, int c)
+template <int NT, class T>
+__device__ __forceinline__ void spd_prep_operands(typename TileGeo<T>::vec4 (&acc)[NT][NT], T (&bop)[NT], int kb, int q, int c)
 {
-    const int tK = kb >> 2, rK = kb & 3, c0 = 4 * (kb & 3);
-    const bool panel_lane = (c >= c0) && (c < c0 + 4);
-    const bool diag_lane = panel_lane && (c - c0 == q);
-    bop[tK] = panel_lane ? (diag_lane ? -1.0 : 0.0) : bop[tK];
+    typedef TileGeo<T> G;
+    const int tK = kb >> 2, rK = kb & 3;
+    const bool panel_lane = G::blk(c) == rK;
+    const bool diag_lane = panel_lane && (G::piv(c) == q);
+    bop[tK] = panel_lane ? (diag_lane ? (T)-1 : (T)0) : bop[tK];
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         if (ti < tK) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ti][tK][r] = panel_lane ? 0.0 : acc[ti][tK][r];
+        for (int r = 0; r < 4; ++r) acc[ti][tK][r] = panel_lane ? (T)0 : acc[ti][tK][r];
     }
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) {
         if (tj > tK) continue;
-        acc[tK][tj][rK] = 0.0;
+        acc[tK][tj][rK] = (T)0;
     }
 }
 

@@ -316,29 +316,28 @@ __global__ __launch_bounds__(64, 4) void matinv_gj_tile_f32(BatchRef<const float
 // (W[I,K] = W[K,I]^T), which already sit in A-operand lane order.
 // The upper triangle of the result is produced at the end by transposing each off-diagonal tile through LDS.
 // Rejected (some pivot <= 0: not SPD, or NaN): work list -> LDS Cholesky kernel, which also reports info exactly.
-template <int NT, bool FULL>
-__global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
-                                                                          int *info, int n_rt, unsigned batch,
-                                                                          int *work_count, int *work_list)
+template <class T, int NT, bool FULL>
+__device__ __forceinline__ void spd_tile_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
+                                              int *work_count, int *work_list, T *panel)
 {
+    typedef TileGeo<T> G;
+    typedef typename G::vec4 vec4;
     constexpr int N = 16 * NT;
     constexpr int NKB = 4 * NT;
-    constexpr int TSTRIDE = 17;  // padded row stride of the 16x16 transpose buffer (conflict-free ds_read_b64)
-    constexpr int LDS_DOUBLES = (N * 4 > 16 * TSTRIDE) ? N * 4 : 16 * TSTRIDE;
+    constexpr int TSTRIDE = 17;  // padded row stride of the 16x16 transpose buffer (conflict-free reads)
     const int n = FULL ? N : n_rt;
-    __shared__ __attribute__((aligned(16))) double panel[LDS_DOUBLES];
     const int l = threadIdx.x;
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
-        const double *A = Ain.at_uniform(mat);
-        double *X = Xout.at_uniform(mat);
+        const T *A = Ain.at_uniform(mat);
+        T *X = Xout.at_uniform(mat);
         int q = l >> 4, c = l & 15;
         const unsigned lane_off = (unsigned)((l >> 4) * n + (l & 15));
         asm volatile("" : "+v"(q), "+v"(c));  // see matinv_gj_tile_f64
 
         // W = A^T tile layout as in the Gauss-Jordan kernel; lower tiles only. In the diagonal tiles the strictly
         // upper elements are fetched from their mirror position, so ONLY the lower triangle of A is ever read.
-        v4d acc[NT][NT];
+        vec4 acc[NT][NT];
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -346,57 +345,57 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
                 if (tj > ti) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
-                    double v;
+                    const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
+                    T v;
                     if (ti == tj) {
                         const int hi = row > col ? row : col, lo = row > col ? col : row;
                         // memory element (r_mem, c_mem) of column-major A sits at c_mem*n + r_mem; W[row][col] =
                         // mem[row*n + col] = A[col][row]; its mirror mem[col*n + row]. Lower triangle of A
                         // (r_mem >= c_mem) <=> mem index (small*n + big).
-                        v = (FULL || (row < n && col < n)) ? A[(unsigned)(lo * n + hi)] : ((row == col) ? 1.0 : 0.0);
+                        v = (FULL || (row < n && col < n)) ? A[(unsigned)(lo * n + hi)] : ((row == col) ? (T)1 : (T)0);
                     } else {
                         // ti > tj: row > col: W[row][col] = mem[row*n + col] = A[col][row] is in A's UPPER triangle;
                         // take its mirror A[row][col] = mem[col*n + row] instead
-                        v = (FULL || (row < n && col < n)) ? A[(unsigned)(col * n + row)] : 0.0;
+                        v = (FULL || (row < n && col < n)) ? A[(unsigned)(col * n + row)] : (T)0;
                     }
                     acc[ti][tj][r] = v;
                 }
             }
         (void)lane_off;
         unsigned long long bad = 0;
-        double aop[NT], bop[NT];
+        T aop[NT], bop[NT];
 
-        spd_panel_to_lds<NT>(panel, acc, 0, q, c);
+        spd_panel_to_lds<NT, T>(panel, acc, 0, q, c);
         wave_lds_sync();
         {
-            PanelSolve<NT, true> ps0;
+            PanelSolve<NT, true, T> ps0;
 #pragma unroll
-            for (int s = 0; s < PanelSolve<NT, true>::NSTAGE; ++s) ps0.stage(s, panel, 0, q, c, aop, bop, bad);
+            for (int s = 0; s < PanelSolve<NT, true, T>::NSTAGE; ++s) ps0.stage(s, panel, 0, q, c, aop, bop, bad);
         }
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const int tK = kb >> 2;
-            spd_prep_operands<NT>(acc, bop, kb, q, c);
+            spd_prep_operands<NT, T>(acc, bop, kb, q, c);
             if (kb + 1 < NKB) {
                 const int tn = (kb + 1) >> 2;
                 // (a) the tiles the next panel is read from: column tn (ti >= tn) and row tn (tj < tn)
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti) {
                     if (ti < tn) continue;
-                    acc[ti][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tn], acc[ti][tn], 0, 0, 0);
+                    acc[ti][tn] = G::mfma(aop[ti], bop[tn], acc[ti][tn]);
                 }
 #pragma unroll
                 for (int tj = 0; tj < NT; ++tj) {
                     if (tj >= tn) continue;
-                    acc[tn][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tn], bop[tj], acc[tn][tj], 0, 0, 0);
+                    acc[tn][tj] = G::mfma(aop[tn], bop[tj], acc[tn][tj]);
                 }
                 // (b) the other lower tiles, pinned between the pieces of the next panel: 2 MFMAs cover the latency of
                 //     (a), then the panel is staged, then the remaining MFMAs are spread evenly over the solve stages.
                 //     Everything below is fully unrolled: the counters fold to literals.
                 constexpr int NB = NT * (NT + 1) / 2 - NT;
-                constexpr int NS = PanelSolve<NT, true>::NSTAGE;
-                double aop_next[NT], bop_next[NT];
-                PanelSolve<NT, true> ps;
+                constexpr int NS = PanelSolve<NT, true, T>::NSTAGE;
+                T aop_next[NT], bop_next[NT];
+                PanelSolve<NT, true, T> ps;
                 int count = 0, ev = 0;  // MFMAs of (b) issued so far; next event (0 = stage the panel, 1 + s = stage s)
                 auto run_events = [&](bool flush) {
 #pragma unroll
@@ -407,7 +406,7 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
                             __builtin_amdgcn_sched_barrier(0);
                             if (e == 0) {
                                 wave_lds_sync();
-                                spd_panel_to_lds<NT>(panel, acc, kb + 1, q, c);
+                                spd_panel_to_lds<NT, T>(panel, acc, kb + 1, q, c);
                                 wave_lds_sync();
                             } else {
                                 ps.stage(e - 1, panel, kb + 1, q, c, aop_next, bop_next, bad);
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
 #pragma unroll
                     for (int tj = 0; tj < NT; ++tj) {
                         if (tj > ti || ti == tn || tj == tn) continue;
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc[ti][tj], 0, 0, 0);
+                        acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
                         ++count;
                         run_events(false);
                     }
@@ -436,7 +435,7 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
 #pragma unroll
                     for (int tj = 0; tj < NT; ++tj) {
                         if (tj > ti) continue;
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc[ti][tj], 0, 0, 0);
+                        acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
                     }
             }
             (void)tK;
@@ -452,19 +451,19 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
                     if (tj > ti) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+                        const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
                         if (FULL || (row < n && col < n)) X[(unsigned)(row * n + col)] = -acc[ti][tj][r];
                     }
                     if (tj < ti) {
                         wave_lds_sync();
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) panel[(4 * r + q) * TSTRIDE + c] = -acc[ti][tj][r];
+                        for (int r = 0; r < 4; ++r) panel[G::trow(r, q) * TSTRIDE + c] = -acc[ti][tj][r];
                         wave_lds_sync();
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             // element (row 16tj + 4r + q, col 16ti + c) of the result = tile(ti,tj)[c][4r + q]
-                            const int row = 16 * tj + 4 * r + q, col = 16 * ti + c;
-                            const double v = panel[c * TSTRIDE + 4 * r + q];
+                            const int row = 16 * tj + G::trow(r, q), col = 16 * ti + c;
+                            const T v = panel[c * TSTRIDE + G::trow(r, q)];
                             if (FULL || (row < n && col < n)) X[(unsigned)(row * n + col)] = v;
                         }
                     }
@@ -476,6 +475,25 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
         }
         wave_lds_sync();
     }
+}
+
+
+template <int NT, bool FULL>
+__global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
+                                                                          int *info, int n_rt, unsigned batch,
+                                                                          int *work_count, int *work_list)
+{
+    // the LDS buffer serves both as the [row][4] panel and as the padded 16x16 transpose buffer
+    __shared__ __attribute__((aligned(16))) double panel[(16 * NT * 4 > 16 * 17) ? 16 * NT * 4 : 16 * 17];
+    spd_tile_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
+}
+
+template <int NT, bool FULL>
+__global__ __launch_bounds__(64, 4) void matinv_spd_tile_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
+                                                            int n_rt, unsigned batch, int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) float panel[(16 * NT * 4 > 16 * 17) ? 16 * NT * 4 : 16 * 17];
+    spd_tile_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -567,15 +585,42 @@ bool spd_tile_supports(int n);
 template <>
 bool spd_tile_supports<double>(int n) { return n >= 1 && n <= 64; }
 template <>
-bool spd_tile_supports<float>(int) { return false; }
+bool spd_tile_supports<float>(int n) { return n >= 1 && n <= 64; }
 
 template <class T>
 hipError_t launch_spd_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 template <>
-hipError_t launch_spd_tile<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t)
+hipError_t launch_spd_tile<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info,
+                                  hipStream_t stream)
 {
-    return hipErrorInvalidValue;
+    if (!spd_tile_supports<float>(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int nt = (n + 15) / 16;
+    const unsigned grid = (unsigned)(batch < 256u * 16u * 4u ? batch : 256u * 16u * 4u);
+    const unsigned b = (unsigned)batch;
+#define SPD_LAUNCH_F32(NT_)                                                                                           \
+    if (n == 16 * NT_)                                                                                                \
+        hipLaunchKernelGGL((matinv_spd_tile_f32<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((matinv_spd_tile_f32<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1)
+    switch (nt) {
+    case 1: SPD_LAUNCH_F32(1); break;
+    case 2: SPD_LAUNCH_F32(2); break;
+    case 3: SPD_LAUNCH_F32(3); break;
+    default: SPD_LAUNCH_F32(4); break;
+    }
+#undef SPD_LAUNCH_F32
+    e = hipGetLastError();
+    if (e == hipSuccess) e = launch_chol_lds_worklist<float>(n, A, X, ws, ws + 1, info, stream);
+    hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
 }
+
 template <>
 hipError_t launch_spd_tile<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
                                    hipStream_t stream)
@@ -610,8 +655,15 @@ hipError_t launch_spd_tile<double>(int n, BatchRef<const double> A, BatchRef<dou
 
 const char *name_spd_tile(bool f64, int n)
 {
-    if (!f64) return "";
     const bool full = (n % 16) == 0;
+    if (!f64) {
+        switch ((n + 15) / 16) {
+        case 1: return full ? "matinv_spd_tile_f32<1, true>" : "matinv_spd_tile_f32<1, false>";
+        case 2: return full ? "matinv_spd_tile_f32<2, true>" : "matinv_spd_tile_f32<2, false>";
+        case 3: return full ? "matinv_spd_tile_f32<3, true>" : "matinv_spd_tile_f32<3, false>";
+        default: return full ? "matinv_spd_tile_f32<4, true>" : "matinv_spd_tile_f32<4, false>";
+        }
+    }
     switch ((n + 15) / 16) {
     case 1: return full ? "matinv_spd_tile_f64<1, true>" : "matinv_spd_tile_f64<1, false>";
     case 2: return full ? "matinv_spd_tile_f64<2, true>" : "matinv_spd_tile_f64<2, false>";

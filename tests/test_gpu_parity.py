@@ -265,6 +265,7 @@ def test_fp32_vs_fp64_oracle(n, family):
     want, _ = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT)
     cond = max(np.linalg.cond(m) for m in as_mats(a, n))
     for algo in (GJ, CH):
+        # (the Cholesky side always goes through the automatic choice: SPD tile kernel for n <= 64, LDS beyond)
         got = gpu_inverse(a.astype(np.float32), n, algo, k if algo == GJ else api.KERNEL_AUTO).astype(np.float64)
         x, y = got.reshape(-1, n * n), want.reshape(-1, n * n)
         fro = np.linalg.norm(x - y, axis=1) / np.linalg.norm(y, axis=1)
