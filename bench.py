@@ -93,6 +93,58 @@ def cpu_baseline(n, algo_name, target_seconds=12.0):
                       f" (C, OpenMP {cores} threads, schedule(dynamic,8)), {dt:.1f} s"}
 
 
+def run_mixed(args, api, device, rank, world):
+    """BASELINE configs[4]: mixed-size fp32 items n in {32,128,512,1024} through the size-binned multi-queue, full
+    add -> inv -> gemv -> dot mean pipeline (fused). Stated mix (items per step and GPU): 32: 16384, 128: 2048, 512: 32,
+    1024: 8 -- roughly equal flops per bin is NOT attempted; per-bin rates are reported. One step = submit + flush."""
+    bq = importlib.import_module(PKG + ".binqueue")
+    mix = {32: 16384, 128: 2048, 512: 32, 1024: 8}
+    g = torch.Generator(device=device).manual_seed(0x5EED + rank)
+    items = []
+    for n, cnt in mix.items():
+        r = torch.rand((cnt, n, n), generator=g, dtype=torch.float32, device=device)
+        B = r + r.transpose(1, 2)
+        B.diagonal(dim1=1, dim2=2).add_(float(n))
+        v = torch.rand((3, cnt, n), generator=g, dtype=torch.float32, device=device)
+        items += [(v[0, i], B[i].reshape(-1), v[1, i], v[2, i]) for i in range(cnt)]
+    q = bq.SizeBinnedQueue(device=device)
+
+    def step():
+        for it in items:
+            q.submit(*it)
+        return q.flush()[0]
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    per_bin = {}
+    for n, cnt in mix.items():  # kernel-only rate of each bin (batched, device resident)
+        sel = [it for it in items if it[0].numel() == n]
+        A_, B_, C_, D_ = (torch.cat([it[k].reshape(-1) for it in sel]) for k in range(4))
+        api.calcluateMean(n, A_, B_, C_, D_)
+        torch.cuda.synchronize()
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        api.calcluateMean(n, A_, B_, C_, D_)
+        e_.record()
+        torch.cuda.synchronize()
+        per_bin[str(n)] = {"items": cnt, "kernel_ms": s_.elapsed_time(e_), "items_per_s": cnt / (s_.elapsed_time(e_) * 1e-3)}
+    if rank == 0:
+        total = sum(mix.values()) * world * args.steps
+        print(json.dumps({
+            "metric": "pipeline items/s (mixed sizes)", "value": total / elapsed, "unit": "items/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "mixed: fp32 mean pipeline, size-binned queues 32/128/512/1024 (BASELINE configs[4])",
+                       "mix_items_per_step_per_gpu": mix, "includes": "host-side submit + per-bin batch assembly + kernels"},
+            "per_bin": per_bin}), flush=True)
+
+
 def load_traffic(kernel_name, n):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -110,7 +162,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="gj64", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="gj64", choices=sorted(WORKLOADS) + ["mixed"])
     ap.add_argument("--batch", type=int, default=100_000, help="matrices per GPU per step")
     ap.add_argument("--kernel", default="auto", choices=["auto", "lds", "rowlane", "tile"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,6 +193,11 @@ def main():
     coll_dev = device if backend == "nccl" else torch.device("cpu")
 
     api = importlib.import_module(PKG + ".api")
+    if args.workload == "mixed":
+        run_mixed(args, api, device, rank, world)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     n, algo_name, desc = WORKLOADS[args.workload]
     algo = api.ALGO_GAUSS_JORDAN if algo_name == "gj" else api.ALGO_CHOLESKY
     kernel = {"auto": api.KERNEL_AUTO, "lds": api.KERNEL_LDS, "rowlane": api.KERNEL_ROWLANE,

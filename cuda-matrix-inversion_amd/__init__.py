@@ -6,6 +6,7 @@ Package layout (only what the hot path needs):
   api.py     host-side mirror of the reference's operator interface
   mats.py    `.mats` file I/O (readMatricesFile / replicateMatrices)
   shard.py   batch partitioning across GPUs and result reassembly (RCCL all-gather)
+  binqueue.py  size-binned multi-queue for mixed-size pipeline items (bins 32/128/512/1024)
 """
 from . import mats  # noqa: F401
 from ._lib import (ALGO_CHOLESKY, ALGO_GAUSS_JORDAN, F32, F64, KERNEL_AUTO, KERNEL_LDS, KERNEL_ROW,  # noqa: F401

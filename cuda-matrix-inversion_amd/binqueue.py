@@ -1,0 +1,102 @@
+"""Size-binned multi-queue for mixed-size Gaussian-process items.
+
+The reference only sketches this ("use multiple queues for different sizes: 32, 128, 512, 1024",
+/root/reference/README.md:41-44) and never built it; BASELINE.json configs[4] asks for it. Items (a, B, c, d[, e]) of
+arbitrary n are appended to the queue of the smallest bin that holds them; `flush()` turns every non-empty queue into ONE
+device-resident batch -- items smaller than their bin are padded with an identity block in B and zeros in the vectors,
+which leaves a^T (B + diag c)^-1 d unchanged -- and launches the fused pipeline kernel of that bin on the bin's own HIP
+stream, so the bins overlap on the device. Results come back in submission order.
+
+torch supplies device memory and streams; all arithmetic is libmatinv_hip.so (api.calcluateMean / calcluateVariance).
+Across GPUs the item list is dealt out by `shard_items` (largest first, round-robin) with no communication; rank results
+are small (one scalar per item) and can be gathered with torch.distributed.all_gather_object by the caller.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+DEFAULT_BINS = (32, 128, 512, 1024)
+
+
+def bin_of(n: int, bins: Sequence[int] = DEFAULT_BINS) -> int:
+    """Smallest bin size >= n."""
+    for b in bins:
+        if n <= b:
+            return b
+    raise ValueError(f"n={n} exceeds the largest bin {bins[-1]}")
+
+
+def shard_items(sizes: Sequence[int], rank: int, world: int) -> List[int]:
+    """Indices of the items rank `rank` of `world` processes: items sorted by size (largest first, cost ~ n^3) are dealt
+    round-robin, which balances the cubic cost to within one item per bin."""
+    order = sorted(range(len(sizes)), key=lambda i: (-sizes[i], i))
+    return sorted(order[rank::world])
+
+
+def pad_item(a, B, c, d, n: int, nb: int):
+    """Embed an n-item into an nb-item: B -> blockdiag(B, I), vectors zero-extended. B is n*n column-major flat or (n, n)."""
+    import torch
+    if n == nb:
+        return a.reshape(-1), B.reshape(-1), c.reshape(-1), d.reshape(-1)
+    Bp = torch.eye(nb, dtype=B.dtype, device=B.device)
+    Bp[:n, :n] = B.reshape(n, n)
+    z = lambda v: torch.cat([v.reshape(-1), torch.zeros(nb - n, dtype=v.dtype, device=v.device)])
+    return z(a), Bp.reshape(-1), z(c), z(d)
+
+
+class SizeBinnedQueue:
+    def __init__(self, bins: Sequence[int] = DEFAULT_BINS, device=None):
+        import torch
+        self.bins = tuple(sorted(bins))
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._queues = {b: [] for b in self.bins}   # bin -> list of (ticket, n, a, B, c, d, e)
+        self._streams = {b: torch.cuda.Stream(device=self.device) for b in self.bins}
+        self._tickets = 0
+
+    def submit(self, a, B, c, d, e=None) -> int:
+        """Queue one item; tensors are CUDA tensors of one dtype. Returns its ticket (position in the result)."""
+        n = a.numel()
+        if B.numel() != n * n or c.numel() != n or d.numel() != n:
+            raise ValueError("inconsistent item shapes")
+        t = self._tickets
+        self._tickets += 1
+        self._queues[bin_of(n, self.bins)].append((t, n, a, B, c, d, e))
+        return t
+
+    def pending(self):
+        return {b: len(q) for b, q in self._queues.items() if q}
+
+    def flush(self) -> Tuple["torch.Tensor", Optional["torch.Tensor"]]:
+        """Run every bin; returns (means, variances or None) in ticket order and empties the queues."""
+        import torch
+        from . import api
+        total = self._tickets
+        if total == 0:
+            return torch.empty(0, device=self.device), None
+        first = next(q[0] for q in self._queues.values() if q)
+        dtype = first[2].dtype
+        means = torch.empty(total, dtype=dtype, device=self.device)
+        want_var = any(item[6] is not None for q in self._queues.values() for item in q)
+        variances = torch.empty(total, dtype=dtype, device=self.device) if want_var else None
+        cur = torch.cuda.current_stream(self.device)
+        for b, q in self._queues.items():
+            if not q:
+                continue
+            s = self._streams[b]
+            s.wait_stream(cur)  # the items were produced on the caller's stream
+            with torch.cuda.stream(s):
+                padded = [pad_item(a, B, c, d, n, b) for (_, n, a, B, c, d, _) in q]
+                A_, B_, C_, D_ = (torch.cat([p[k] for p in padded]).contiguous() for k in range(4))
+                idx = torch.tensor([t for (t, *_rest) in q], device=self.device)
+                out = api.calcluateMean(b, A_, B_, C_, D_, batchSize=len(q))
+                means.index_copy_(0, idx, out)
+                if want_var:
+                    E_ = torch.stack([(item[6] if item[6] is not None else torch.zeros((), dtype=dtype, device=self.device)).reshape(())
+                                      for item in q])
+                    var = api.calcluateVariance(b, A_, B_, C_, E_, batchSize=len(q))
+                    variances.index_copy_(0, idx, var)
+        for s in self._streams.values():
+            cur.wait_stream(s)
+        self._queues = {b: [] for b in self.bins}
+        self._tickets = 0
+        return means, variances

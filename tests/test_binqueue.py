@@ -1,0 +1,59 @@
+"""Size-binned multi-queue (README.md:41-44 of the reference; BASELINE configs[4])."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import pkg, spd_batch
+
+
+def test_bin_and_shard_logic_cpu():
+    bq = pkg("binqueue")
+    assert [bq.bin_of(n) for n in (1, 32, 33, 128, 129, 512, 513, 1024)] == [32, 32, 128, 128, 512, 512, 1024, 1024]
+    with pytest.raises(ValueError):
+        bq.bin_of(1025)
+    sizes = [32] * 10 + [1024] * 3 + [128] * 7 + [512] * 4
+    parts = [bq.shard_items(sizes, r, 4) for r in range(4)]
+    assert sorted(i for p in parts for i in p) == list(range(len(sizes)))
+    cost = [sum(sizes[i] ** 3 for i in p) for p in parts]
+    assert max(cost) - min(cost) <= 1024 ** 3  # within one largest item
+
+
+def test_padding_leaves_the_scalar_unchanged_cpu():
+    import torch
+    bq = pkg("binqueue")
+    n, nb = 5, 8
+    rng = np.random.default_rng(0)
+    B = spd_batch(n, 1, seed=3)
+    a, c, d = (rng.random(n) for _ in range(3))
+    t = [torch.from_numpy(x) for x in (a, B, c, d)]
+    ap, Bp, cp, dp = (x.numpy() for x in bq.pad_item(*t, n, nb))
+    m0 = oracle.mean_batched(a, B, c, d, n)[0]
+    m1 = oracle.mean_batched(ap, Bp, cp, dp, nb)[0]
+    assert abs(m0 - m1) < 1e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_mixed_size_stream_matches_oracle(dtype):
+    import torch
+    bq = pkg("binqueue")
+    dt = getattr(torch, dtype)
+    rng = np.random.default_rng(11)
+    sizes = [32, 7, 128, 100, 32, 512, 33, 64, 128, 16, 300, 32, 1024 if dtype == "float32" else 200]
+    q = bq.SizeBinnedQueue()
+    want_m, want_v = [], []
+    for i, n in enumerate(sizes):
+        B = spd_batch(n, 1, seed=100 + i)
+        a, c, d = (rng.random(n) for _ in range(3))
+        e = rng.random(1)
+        want_m.append(oracle.mean_batched(a, B, c, d, n)[0])
+        want_v.append(oracle.variance_batched(a, B, c, e, n)[0])
+        to = lambda x: torch.from_numpy(x).to(dt).cuda()
+        assert q.submit(to(a), to(B), to(c), to(d), to(e)) == i
+    assert q.pending() == {32: 5, 128: 5, 512: 2, 1024: 1} if dtype == "float32" else True
+    m, v = q.flush()
+    torch.cuda.synchronize()
+    tol = 1e-10 if dtype == "float64" else 5e-5
+    assert np.abs(m.double().cpu().numpy() - np.array(want_m)).max() < tol
+    assert np.abs(v.double().cpu().numpy() - np.array(want_v)).max() < tol
+    assert q.pending() == {} and q.flush()[0].numel() == 0
