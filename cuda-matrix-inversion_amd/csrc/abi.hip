@@ -163,6 +163,72 @@ void timer_log(const char *prefix, const char *phase, size_t batch, int n, doubl
     printf("%s_%s,%zu,%d,%.4f,%lu\r\n", prefix, phase, batch, n, ms, (unsigned long)(ms * 1e6));
 }
 
+// Large host batches: the caller's two buffers are page-locked in place (hipHostRegister) and the batch is cut into chunks
+// that rotate over a few streams -- chunk i+1 uploads while chunk i is inverted and chunk i-1 downloads (PCIe is full
+// duplex; the simple path below does H2D, kernel, D2H strictly one after the other, through the runtime's pageable
+// staging). Device memory is chunk-sized, so a host batch larger than HBM also works.
+// Returns MATINV_ERR_UNSUPPORTED (without touching the output) when the buffers cannot be registered; the caller then
+// takes the simple path.
+template <class T>
+int inverse_host_pipelined(int algo, int n, const T *hA, T *hAinv, size_t batch, int *info, int kernel, double &ms_total)
+{
+    constexpr int NS = 3;  // streams / chunk slots in flight
+    const size_t mat = (size_t)n * n, bytes_mat = mat * sizeof(T);
+    size_t chunk = (size_t)(48u << 20) / bytes_mat;  // ~48 MiB per chunk
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    const double t0 = now_ms();
+    if (hipHostRegister(const_cast<T *>(hA), batch * bytes_mat, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return MATINV_ERR_UNSUPPORTED;
+    }
+    if (hipHostRegister(hAinv, batch * bytes_mat, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostUnregister(const_cast<T *>(hA));
+        return MATINV_ERR_UNSUPPORTED;
+    }
+    hipStream_t st[NS] = {};
+    T *dA[NS] = {}, *dX[NS] = {};
+    int *dI[NS] = {};
+    hipError_t e = hipSuccess;
+    int rc = MATINV_OK;
+    for (int s = 0; s < NS && e == hipSuccess; ++s) {
+        e = hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(&dA[s], chunk * bytes_mat);
+        if (e == hipSuccess) e = hipMalloc(&dX[s], chunk * bytes_mat);
+        if (e == hipSuccess && info) e = hipMalloc(&dI[s], chunk * sizeof(int));
+    }
+    size_t slot = 0;
+    for (size_t off = 0; off < batch && e == hipSuccess && rc == MATINV_OK; off += chunk, ++slot) {
+        const int s = (int)(slot % NS);
+        const size_t cnt = (batch - off < chunk) ? batch - off : chunk;
+        // the slot's previous chunk has fully left the device once its stream is idle (same stream: in order anyway)
+        e = hipMemcpyAsync(dA[s], hA + off * mat, cnt * bytes_mat, hipMemcpyHostToDevice, st[s]);
+        if (e != hipSuccess) break;
+        rc = inverse_strided<T>(algo, n, dA[s], mat, dX[s], mat, cnt, info ? dI[s] : nullptr, st[s], kernel);
+        if (rc != MATINV_OK) break;
+        e = hipMemcpyAsync(hAinv + off * mat, dX[s], cnt * bytes_mat, hipMemcpyDeviceToHost, st[s]);
+        if (e == hipSuccess && info)
+            e = hipMemcpyAsync(info + off, dI[s], cnt * sizeof(int), hipMemcpyDeviceToHost, st[s]);
+    }
+    for (int s = 0; s < NS; ++s) {
+        if (st[s]) {
+            hipError_t es = hipStreamSynchronize(st[s]);
+            if (e == hipSuccess) e = es;
+            (void)hipStreamDestroy(st[s]);
+        }
+        if (dA[s]) (void)hipFree(dA[s]);
+        if (dX[s]) (void)hipFree(dX[s]);
+        if (dI[s]) (void)hipFree(dI[s]);
+    }
+    (void)hipHostUnregister(const_cast<T *>(hA));
+    (void)hipHostUnregister(hAinv);
+    ms_total = now_ms() - t0;
+    if (rc != MATINV_OK) return rc;
+    if (e != hipSuccess) return fail_hip(e, "pipelined host<->device transfer");
+    return MATINV_OK;
+}
+
 template <class T>
 int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int *info, const char *log_prefix,
                  int kernel = MATINV_KERNEL_AUTO)
@@ -173,6 +239,23 @@ int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int
     int rc = check_device();
     if (rc) return rc;
     const size_t elems = (size_t)n * n * batch;  // size_t: 1M x 64 x 64 overflows the reference's int index
+    {
+        // pipelined path for batches worth it (>= 128 MiB per direction); MATINV_HOST_PIPELINE=0/1 forces it off/on
+        static const int mode = []() {
+            const char *s = getenv("MATINV_HOST_PIPELINE");
+            return s && *s ? atoi(s) : -1;
+        }();
+        const bool big = elems * sizeof(T) >= ((size_t)128 << 20);
+        if (hA != hAinv && (mode == 1 || (mode < 0 && big))) {
+            double ms = 0;
+            const int prc = inverse_host_pipelined<T>(algo, n, static_cast<const T *>(hA), static_cast<T *>(hAinv), batch, info,
+                                                      kernel, ms);
+            if (prc != MATINV_ERR_UNSUPPORTED) {
+                if (prc == MATINV_OK && detailed_logging() && log_prefix) timer_log(log_prefix, "pipelined_total", batch, n, ms);
+                return prc;
+            }
+        }
+    }
     T *dA = nullptr, *dX = nullptr;
     int *dInfo = nullptr;
     hipError_t e;
