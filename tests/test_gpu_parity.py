@@ -466,3 +466,32 @@ def test_full_size_properties(n, batch, algo):
     sub = a[idx].reshape(-1).cpu().numpy()
     want, _ = oracle.inverse_batched(sub, n, oracle.ALGO_GJ_PIVOT if algo == GJ else oracle.ALGO_CHOLESKY)
     assert rel_err(xm[idx].reshape(-1).cpu().numpy(), want, n) < 1e-10
+
+
+def test_batch_beyond_32bit_element_offsets():
+    """BASELINE configs[3] (1 M x 64x64 fp64) on one GPU, slightly enlarged so that ELEMENT offsets exceed 2^32 (the
+    reference indexes with int, src/gauss/batched_invert.cu:130, and overflows at 2^31). 36 GB per operand."""
+    n, batch, chunk = 64, 1_100_000, 50_000
+    assert batch * n * n > 2 ** 32
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2.2 * batch * n * n * 8:
+        pytest.skip("not enough free device memory")
+    a = torch.empty(batch * n * n, dtype=torch.float64, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for i in range(0, batch, chunk):
+        r = torch.rand((chunk, n, n), generator=g, dtype=torch.float64, device="cuda")
+        r = r + r.transpose(1, 2)
+        r.diagonal(dim1=1, dim2=2).add_(float(n))
+        a[i * n * n:(i + chunk) * n * n] = r.reshape(-1)
+    info = torch.empty(batch, dtype=torch.int32, device="cuda")
+    x = api.inverse_batched(a, n, GJ, info=info)
+    assert int((info != 0).sum()) == 0
+    eye = torch.eye(n, dtype=torch.float64, device="cuda")
+    for lo in (0, batch // 2, (2 ** 32) // (n * n) - 500, batch - 1000):
+        am, xm = a.view(batch, n, n)[lo:lo + 1000], x.view(batch, n, n)[lo:lo + 1000]
+        assert float((torch.bmm(am, xm) - eye).abs().max()) < 1e-12
+    idx = torch.tensor([0, batch - 1], device="cuda")
+    want, _ = oracle.inverse_batched(a.view(batch, n * n)[idx].reshape(-1).cpu().numpy(), n)
+    assert rel_err(x.view(batch, n * n)[idx].reshape(-1).cpu().numpy(), want, n) < 1e-10
+    del a, x
+    torch.cuda.empty_cache()
