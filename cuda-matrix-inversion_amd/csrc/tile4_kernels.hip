@@ -19,11 +19,12 @@
 
 namespace matinv {
 
-constexpr int T4_WAVES = 4;
 
-// NT = tiles per dimension (5..8), NC = tile columns per wave = ceil(NT / 4)
-template <int NT, bool FULL>
-__global__ __launch_bounds__(64 * T4_WAVES, FULL ? 2 : 1) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
+// NT = tiles per dimension, T4_WAVES = wavefronts per matrix, NC = tile columns per wave = ceil(NT / T4_WAVES).
+// (Measured and not used: NT = 4 with 2 waves per 64 x 64 matrix, 142 VGPRs, 3 waves per SIMD: 4.7e7 inv/s against 6.1e7
+// for the one-wave kernel of tile_kernels.hip -- the redundant panel solve and the barriers cost more than the occupancy buys.)
+template <int NT, bool FULL, int T4_WAVES = 4>
+__global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
                                                                        int *info, int n_rt, unsigned batch,
                                                                        int *work_count, int *work_list)
 {
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(64 * T4_WAVES, FULL ? 2 : 1) void matinv_gj_tile4_f
 // ------------------------------------------------------------------------------------------------
 bool tile4_supports_f64(int n) { return n > 64 && n <= 128; }
 
+
 hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
                                hipStream_t stream)
 {
@@ -192,9 +194,9 @@ hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double>
     const unsigned b = (unsigned)batch;
 #define T4_LAUNCH(NT_)                                                                                                \
     if (n == 16 * NT_)                                                                                                \
-        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true>), dim3(grid), dim3(64 * T4_WAVES), 0, stream, A, X, info, n, b, ws, ws + 1); \
+        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
     else                                                                                                              \
-        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false>), dim3(grid), dim3(64 * T4_WAVES), 0, stream, A, X, info, n, b, ws, ws + 1)
+        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1)
     switch (nt) {
     case 5: T4_LAUNCH(5); break;
     case 6: T4_LAUNCH(6); break;
