@@ -100,18 +100,22 @@ def run_mixed(args, api, device, rank, world):
     bq = importlib.import_module(PKG + ".binqueue")
     mix = {32: 16384, 128: 2048, 512: 32, 1024: 8}
     g = torch.Generator(device=device).manual_seed(0x5EED + rank)
-    items = []
+    items, chunks = [], []
+    CH = 256  # items arrive in same-size chunks of up to 256 (submit_many); the sizes are interleaved chunk by chunk
     for n, cnt in mix.items():
         r = torch.rand((cnt, n, n), generator=g, dtype=torch.float32, device=device)
         B = r + r.transpose(1, 2)
         B.diagonal(dim1=1, dim2=2).add_(float(n))
         v = torch.rand((3, cnt, n), generator=g, dtype=torch.float32, device=device)
         items += [(v[0, i], B[i].reshape(-1), v[1, i], v[2, i]) for i in range(cnt)]
+        chunks += [(n, v[0, i:i + CH].reshape(-1), B[i:i + CH].reshape(-1), v[1, i:i + CH].reshape(-1), v[2, i:i + CH].reshape(-1))
+                   for i in range(0, cnt, CH)]
+    chunks = [chunks[i] for i in torch.randperm(len(chunks), generator=torch.Generator().manual_seed(1)).tolist()]
     q = bq.SizeBinnedQueue(device=device)
 
     def step():
-        for it in items:
-            q.submit(*it)
+        for ch in chunks:
+            q.submit_many(*ch)
         return q.flush()[0]
 
     for _ in range(max(1, args.warmup)):
@@ -141,7 +145,7 @@ def run_mixed(args, api, device, rank, world):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "mixed: fp32 mean pipeline, size-binned queues 32/128/512/1024 (BASELINE configs[4])",
-                       "mix_items_per_step_per_gpu": mix, "includes": "host-side submit + per-bin batch assembly + kernels"},
+                       "mix_items_per_step_per_gpu": mix, "includes": "host-side submit_many (same-size chunks of <= 256 items, sizes interleaved) + per-bin batch assembly + kernels"},
             "per_bin": per_bin}), flush=True)
 
 

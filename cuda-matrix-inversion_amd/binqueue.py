@@ -35,12 +35,21 @@ def shard_items(sizes: Sequence[int], rank: int, world: int) -> List[int]:
 
 def pad_item(a, B, c, d, n: int, nb: int):
     """Embed an n-item into an nb-item: B -> blockdiag(B, I), vectors zero-extended. B is n*n column-major flat or (n, n)."""
+    return pad_items(a, B, c, d, n, nb, 1)
+
+
+def pad_items(a, B, c, d, n: int, nb: int, count: int):
+    """`count` equally sized n-items (flat, item-major) embedded into nb-items in one shot."""
     import torch
     if n == nb:
         return a.reshape(-1), B.reshape(-1), c.reshape(-1), d.reshape(-1)
-    Bp = torch.eye(nb, dtype=B.dtype, device=B.device)
-    Bp[:n, :n] = B.reshape(n, n)
-    z = lambda v: torch.cat([v.reshape(-1), torch.zeros(nb - n, dtype=v.dtype, device=v.device)])
+    Bp = torch.eye(nb, dtype=B.dtype, device=B.device).repeat(count, 1, 1)
+    Bp[:, :n, :n] = B.reshape(count, n, n)
+
+    def z(v):
+        out = torch.zeros((count, nb), dtype=v.dtype, device=v.device)
+        out[:, :n] = v.reshape(count, n)
+        return out.reshape(-1)
     return z(a), Bp.reshape(-1), z(c), z(d)
 
 
@@ -49,22 +58,29 @@ class SizeBinnedQueue:
         import torch
         self.bins = tuple(sorted(bins))
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self._queues = {b: [] for b in self.bins}   # bin -> list of (ticket, n, a, B, c, d, e)
+        self._queues = {b: [] for b in self.bins}   # bin -> list of chunks (first ticket, count, n, a, B, c, d, e)
         self._streams = {b: torch.cuda.Stream(device=self.device) for b in self.bins}
         self._tickets = 0
 
     def submit(self, a, B, c, d, e=None) -> int:
         """Queue one item; tensors are CUDA tensors of one dtype. Returns its ticket (position in the result)."""
-        n = a.numel()
-        if B.numel() != n * n or c.numel() != n or d.numel() != n:
+        return self.submit_many(a.numel(), a, B, c, d, e, count=1)
+
+    def submit_many(self, n: int, As, Bs, Cs, Ds, Es=None, count: Optional[int] = None) -> int:
+        """Queue `count` items of one size n that already lie back to back (As: count*n, Bs: count*n*n column-major, ...;
+        Es: count scalars or None). Returns the ticket of the first; the rest follow consecutively. No per-item host work."""
+        if count is None:
+            count = As.numel() // n
+        if As.numel() != count * n or Bs.numel() != count * n * n or Cs.numel() != count * n or Ds.numel() != count * n \
+                or (Es is not None and Es.numel() != count):
             raise ValueError("inconsistent item shapes")
         t = self._tickets
-        self._tickets += 1
-        self._queues[bin_of(n, self.bins)].append((t, n, a, B, c, d, e))
+        self._tickets += count
+        self._queues[bin_of(n, self.bins)].append((t, count, n, As, Bs, Cs, Ds, Es))
         return t
 
     def pending(self):
-        return {b: len(q) for b, q in self._queues.items() if q}
+        return {b: sum(ch[1] for ch in q) for b, q in self._queues.items() if q}
 
     def flush(self) -> Tuple["torch.Tensor", Optional["torch.Tensor"]]:
         """Run every bin; returns (means, variances or None) in ticket order and empties the queues."""
@@ -74,9 +90,9 @@ class SizeBinnedQueue:
         if total == 0:
             return torch.empty(0, device=self.device), None
         first = next(q[0] for q in self._queues.values() if q)
-        dtype = first[2].dtype
+        dtype = first[3].dtype
         means = torch.empty(total, dtype=dtype, device=self.device)
-        want_var = any(item[6] is not None for q in self._queues.values() for item in q)
+        want_var = any(ch[7] is not None for q in self._queues.values() for ch in q)
         variances = torch.empty(total, dtype=dtype, device=self.device) if want_var else None
         cur = torch.cuda.current_stream(self.device)
         for b, q in self._queues.items():
@@ -85,15 +101,17 @@ class SizeBinnedQueue:
             s = self._streams[b]
             s.wait_stream(cur)  # the items were produced on the caller's stream
             with torch.cuda.stream(s):
-                padded = [pad_item(a, B, c, d, n, b) for (_, n, a, B, c, d, _) in q]
+                padded = [pad_items(a, B, c, d, n, b, cnt) for (_, cnt, n, a, B, c, d, _) in q]
                 A_, B_, C_, D_ = (torch.cat([p[k] for p in padded]).contiguous() for k in range(4))
-                idx = torch.tensor([t for (t, *_rest) in q], device=self.device)
-                out = api.calcluateMean(b, A_, B_, C_, D_, batchSize=len(q))
+                nitems = sum(ch[1] for ch in q)
+                idx = torch.cat([torch.arange(t, t + cnt, device=self.device) for (t, cnt, *_rest) in q]) \
+                    if len(q) < 64 else torch.tensor([t + i for (t, cnt, *_rest) in q for i in range(cnt)], device=self.device)
+                out = api.calcluateMean(b, A_, B_, C_, D_, batchSize=nitems)
                 means.index_copy_(0, idx, out)
                 if want_var:
-                    E_ = torch.stack([(item[6] if item[6] is not None else torch.zeros((), dtype=dtype, device=self.device)).reshape(())
-                                      for item in q])
-                    var = api.calcluateVariance(b, A_, B_, C_, E_, batchSize=len(q))
+                    E_ = torch.cat([(ch[7].reshape(-1) if ch[7] is not None
+                                     else torch.zeros(ch[1], dtype=dtype, device=self.device)) for ch in q])
+                    var = api.calcluateVariance(b, A_, B_, C_, E_, batchSize=nitems)
                     variances.index_copy_(0, idx, var)
         for s in self._streams.values():
             cur.wait_stream(s)

@@ -368,6 +368,18 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
     }
     if (!lds_family_supports<T>(n)) {
         if (!global_family_supports<T>(n)) return fail(MATINV_ERR_UNSUPPORTED, "pipeline: n=%d exceeds the limit 1024", n);
+        static const bool use_blocked = []() {
+            const char *s = getenv("MATINV_GP_BLOCKED");  // A/B switch for profiling; default on
+            return !(s && *s == '0');
+        }();
+        if (use_blocked && batch <= 65535) {
+            hipError_t eb = launch_gp_blocked<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
+                                                 static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
+                                                 static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,
+                                                 static_cast<hipStream_t>(stream));
+            if (eb != hipSuccess) return fail_hip(eb, "kernel launch");
+            return MATINV_OK;
+        }
         hipError_t eg = launch_gp_global<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
                                             static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
                                             static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,

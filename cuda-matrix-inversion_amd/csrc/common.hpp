@@ -65,6 +65,11 @@ hipError_t launch_gj_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
 template <class T>
 bool rowlane_family_supports(int n);
 
+// blocked multi-launch Cholesky for the fused GP scalars at large n (blocked_gp_kernels.hip)
+template <class T>
+hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                             int *info, hipStream_t stream);
+
 // GLOBAL family (global_kernels.hip): any n <= 1024, working copy in global memory
 template <class T>
 bool global_family_supports(int n);

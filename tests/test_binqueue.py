@@ -57,3 +57,32 @@ def test_mixed_size_stream_matches_oracle(dtype):
     assert np.abs(m.double().cpu().numpy() - np.array(want_m)).max() < tol
     assert np.abs(v.double().cpu().numpy() - np.array(want_v)).max() < tol
     assert q.pending() == {} and q.flush()[0].numel() == 0
+
+
+@pytest.mark.gpu
+def test_submit_many_matches_single_submits():
+    """Chunked submission (same-size items back to back) gives the same results, in ticket order, as item-by-item."""
+    import torch
+    bq = pkg("binqueue")
+    rng = np.random.default_rng(5)
+    groups = [(20, 7), (32, 5), (100, 3), (20, 2), (130, 2)]  # (n, count): padded and exact bins, a bin hit twice
+    q1, q2 = bq.SizeBinnedQueue(), bq.SizeBinnedQueue()
+    want = []
+    for gi, (n, cnt) in enumerate(groups):
+        B = spd_batch(n, cnt, seed=50 + gi)
+        a, c, d = (rng.random(cnt * n) for _ in range(3))
+        e = rng.random(cnt)
+        want += list(oracle.variance_batched(a, B, c, e, n))
+        to = lambda x: torch.from_numpy(x).cuda()
+        ta, tB, tc, td, te = (to(x) for x in (a, B, c, d, e))
+        first = q1.submit_many(n, ta, tB, tc, td, te)
+        assert first == len(want) - cnt
+        for i in range(cnt):
+            q2.submit(ta[i * n:(i + 1) * n], tB[i * n * n:(i + 1) * n * n], tc[i * n:(i + 1) * n], td[i * n:(i + 1) * n], te[i:i + 1])
+    assert q1.pending() == q2.pending() == {32: 14, 128: 3, 512: 2}
+    (m1, v1), (m2, v2) = q1.flush(), q2.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(m1, m2) and torch.equal(v1, v2)
+    assert np.abs(v1.cpu().numpy() - np.array(want)).max() < 1e-10
+    with pytest.raises(ValueError):
+        q1.submit_many(4, ta[:8], tB[:32], tc[:8], td[:7])

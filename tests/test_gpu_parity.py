@@ -225,6 +225,36 @@ def test_large_n_singular_and_fp32():
     assert rel_err(gpu_inverse(b, n, GJ), want, n) < 1e-10
 
 
+@pytest.mark.parametrize("n,batch,dtype", [(142, 7, "f64"), (201, 5, "f64"), (257, 3, "f64"), (500, 3, "f64"), (512, 2, "f32"),
+                                           (1000, 2, "f32"), (1024, 2, "f64")])
+def test_pipeline_large_n_blocked(n, batch, dtype):
+    """Fused mean / variance beyond the LDS limit: blocked multi-launch Cholesky with the vectors as border rows
+    (blocked_gp_kernels.hip); ragged last panel / tile (n not a multiple of 32 or 64), both precisions, and an item
+    that is not positive definite (info = failing column, NaN result, neighbours untouched)."""
+    rng = np.random.default_rng(n)
+    B = spd_batch(n, batch, seed=n + 1)
+    va, vc, vd = (rng.random(batch * n) for _ in range(3))
+    ve = rng.random(batch)
+    wm = oracle.mean_batched(va, B, vc, vd, n)
+    wv = oracle.variance_batched(va, B, vc, ve, n)
+    bad = batch - 1
+    B, vc = B.copy(), vc.copy()
+    B.reshape(batch, n, n)[bad, n // 2, n // 2] = -1e3  # pivot n/2 turns negative (the oracle refuses such input)
+    vc.reshape(batch, n)[bad, n // 2] = 0.0
+    np_t = np.float64 if dtype == "f64" else np.float32
+    t = [dev(x.astype(np_t)) for x in (va, B, vc, vd, ve)]
+    info_m = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    info_v = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    m = api.calcluateMean(n, t[0], t[1], t[2], t[3], info=info_m).cpu().numpy().astype(np.float64)
+    v = api.calcluateVariance(n, t[0], t[1], t[2], t[4], info=info_v).cpu().numpy().astype(np.float64)
+    good = np.arange(batch) != bad
+    tol = 1e-10 if dtype == "f64" else 2e-4
+    assert np.abs(m[good] - wm[good]).max() < tol * max(1.0, np.abs(wm[good]).max())
+    assert np.abs(v[good] - wv[good]).max() < tol * max(1.0, np.abs(wv[good]).max())
+    assert np.isnan(m[bad]) and np.isnan(v[bad])
+    assert info_m.cpu().tolist() == [0] * (batch - 1) + [n // 2 + 1] == info_v.cpu().tolist()
+
+
 def test_randomized_sizes_batches_dtypes():
     """Seeded sweep over odd sizes / batch counts (ragged last wavefront, identity padding, every dispatch boundary):
     n in 1..140, batch in 1..260, both precisions, both algorithms, SPD and general inputs."""
