@@ -95,7 +95,8 @@ class SizeBinnedQueue:
         want_var = any(ch[7] is not None for q in self._queues.values() for ch in q)
         variances = torch.empty(total, dtype=dtype, device=self.device) if want_var else None
         cur = torch.cuda.current_stream(self.device)
-        for b, q in self._queues.items():
+        for b in sorted(self._queues, reverse=True):  # largest bin first: its many small launches overlap the rest
+            q = self._queues[b]
             if not q:
                 continue
             s = self._streams[b]

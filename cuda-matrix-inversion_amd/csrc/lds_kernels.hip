@@ -10,6 +10,7 @@
 //                    /root/reference/src/inverse_cholesky_cpu.c:17-85 and of GPU kernels C4-C7
 //                    (src/inverse_cholesky_gpu.cu:251-312), one launch instead of 4N+1.
 #include "common.hpp"
+#include "chol_block.hpp"
 
 namespace matinv {
 
@@ -170,29 +171,6 @@ template <>
 __device__ __forceinline__ float sqrt_of<float>(float v) { return sqrtf(v); }
 
 // Cholesky building blocks on an LDS-resident matrix a[c*ld + r] (lower triangle significant).
-// phase 1: A = L L^T, right-looking (choleskyDecomposition, inverse_cholesky_cpu.c:17-35; GPU kernels C4+C5,
-// src/inverse_cholesky_gpu.cu:251-283). Returns 0 or k+1 (block-uniform) when pivot k is not positive.
-template <class T>
-__device__ __forceinline__ int chol_factor_lds(T *a, int ld, int n)
-{
-    const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
-    for (int k = 0; k < n; ++k) {
-        const T d = a[k * ld + k];
-        if (!(d > 0)) return k + 1;
-        const T sd = sqrt_of<T>(d);
-        const T rs = (T)1 / sd;
-        __syncthreads();  // everyone has read d before it is overwritten
-        for (int i = k + t; i < n; i += LDS_THREADS) a[k * ld + i] = (i == k) ? sd : a[k * ld + i] * rs;
-        __syncthreads();
-        for (int j = k + 1 + ty; j < n; j += LDS_THREADS / 64) {
-            const T ljk = a[k * ld + j];
-            for (int i = j + tx; i < n; i += 64) a[j * ld + i] -= a[k * ld + i] * ljk;
-        }
-        __syncthreads();
-    }
-    return 0;
-}
-
 // phase 2: L <- L^-1 in place, last column first (inverseLower, inverse_cholesky_cpu.c:37-58; GPU C6 :286-301)
 template <class T>
 __device__ __forceinline__ void tri_inverse_lds(T *a, T *vec, int ld, int n)
@@ -232,7 +210,7 @@ __device__ __forceinline__ void chol_lds_one(const T *A, T *X, int *info_slot, i
     __syncthreads();
 
     if (phases & CHOL_PHASE_FACTOR) {
-        const int bad = chol_factor_lds(a, ld, n);
+        const int bad = chol_factor_lds(a, ld, n, n);
         if (bad) {
             if (info_slot && t == 0) *info_slot = bad;
             fill_nan(X, n);
@@ -288,46 +266,32 @@ template <class T>
 __device__ __forceinline__ void gp_lds_one(const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out,
                                            int *info, int n, size_t k_mat, unsigned char *smem_raw, T *s_part)
 {
-    const int ld = lds_ld(n);
+    // the vectors travel as border ROWS n (a) and n+1 (d) of the LDS matrix: after the factorisation they hold
+    // (L^-1 a)^T and (L^-1 d)^T, so the answer is one dot product -- no separate substitution sweeps
+    const bool variance = (Ds == nullptr);
+    const int nrows = n + (variance ? 1 : 2);
+    const int ld = (n + 2) | 1;  // n * ld fits the LDS budget of lds_bytes() (matrix + 3 vectors)
     T *a = reinterpret_cast<T *>(smem_raw);
-    T *u = a + (size_t)n * ld;
-    T *w = u + n;
     const T *B = Bs + k_mat * (size_t)n * n;
     const int t = threadIdx.x;
     const int tx = t & 63, ty = t >> 6;
-    const bool variance = (Ds == nullptr);
 
-    for (int c = ty; c < n; c += LDS_THREADS / 64)
-        for (int r = tx; r < n; r += 64) a[c * ld + r] = B[(size_t)c * n + r];
-    for (int i = t; i < n; i += LDS_THREADS) {
-        u[i] = As[k_mat * n + i];
-        w[i] = variance ? (T)0 : Ds[k_mat * n + i];
+    for (int c = ty; c < n; c += LDS_THREADS / 64) {
+        const T cc = Cs[k_mat * n + c], uc = As[k_mat * n + c], wc = variance ? (T)0 : Ds[k_mat * n + c];
+        for (int r = tx; r < n; r += 64) a[c * ld + r] = B[(size_t)c * n + r] + ((r == c) ? cc : (T)0);  // addDiagonal, gauss_bench.cu:38-43
+        if (tx == 0) a[c * ld + n] = uc;
+        if (tx == 1 && !variance) a[c * ld + n + 1] = wc;
     }
     __syncthreads();
-    for (int i = t; i < n; i += LDS_THREADS) a[i * ld + i] += Cs[k_mat * n + i];  // addDiagonal, gauss_bench.cu:38-43
-    __syncthreads();
 
-    const int bad = chol_factor_lds(a, ld, n);
+    const int bad = chol_factor_lds(a, ld, n, nrows);
     if (bad) {
         if (info && t == 0) info[k_mat] = bad;
         if (t == 0) out[k_mat] = nan_of<T>();
         return;
     }
-    // forward substitution, column oriented: x_k /= L[k][k]; x_i -= L[i][k] x_k (i > k)
-    for (int k = 0; k < n; ++k) {
-        const T rk = (T)1 / a[k * ld + k];
-        const T uk = u[k] * rk, wk = w[k] * rk;
-        __syncthreads();
-        if (t == 0) { u[k] = uk; w[k] = wk; }
-        for (int i = k + 1 + t; i < n; i += LDS_THREADS) {
-            const T l = a[k * ld + i];
-            u[i] -= l * uk;
-            w[i] -= l * wk;
-        }
-        __syncthreads();
-    }
     T part = 0;
-    for (int i = t; i < n; i += LDS_THREADS) part += u[i] * (variance ? u[i] : w[i]);
+    for (int i = t; i < n; i += LDS_THREADS) part += a[i * ld + n] * a[i * ld + (variance ? n : n + 1)];
     for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off);
     if (tx == 0) s_part[ty] = part;
     __syncthreads();

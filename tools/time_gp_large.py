@@ -7,7 +7,7 @@ import torch
 api = importlib.import_module("cuda-matrix-inversion_amd.api")
 
 for dtype in (torch.float32, torch.float64):
-    for n, batch in ((256, 256), (512, 64), (512, 8), (1024, 32), (1024, 8)):
+    for n, batch in ((128, 2048), (100, 2048), (200, 512), (256, 256), (512, 64), (512, 8), (1024, 32), (1024, 8)):
         g = torch.Generator(device="cuda").manual_seed(n)
         R = torch.rand(batch, n, n, generator=g, device="cuda", dtype=dtype)
         B = (R @ R.transpose(1, 2) + n * torch.eye(n, device="cuda", dtype=dtype)).reshape(-1)
