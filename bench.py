@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "cuda-matrix-inversion_amd"
 
+F64_MFMA_PEAK_TFLOPS = 78.6  # 1024 SIMDs x 32 flop/clk (v_mfma_f64_16x16x4_f64: 2048 flop per 64-cycle issue) x 2.4 GHz
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 WORKLOADS = {
@@ -147,6 +148,33 @@ def run_mixed(args, api, device, rank, world):
             "config": {"workload": "mixed: fp32 mean pipeline, size-binned queues 32/128/512/1024 (BASELINE configs[4])",
                        "mix_items_per_step_per_gpu": mix, "includes": "host-side submit_many (same-size chunks of <= 256 items, sizes interleaved) + per-bin batch assembly + kernels"},
             "per_bin": per_bin}), flush=True)
+
+
+def mfma_flops_per_inversion(algo_name, n):
+    """fp64 flops the MFMA tile kernels issue per matrix (None for the families without MFMA): a blocked sweep of 4*NT
+    rank-4 steps over NT^2 tiles (Gauss-Jordan: all tiles = 2 n^3 flop) or over the NT(NT+1)/2 lower tiles (SPD sweep),
+    2048 flop per v_mfma_f64_16x16x4_f64."""
+    if n <= 16 or n > 128 or (algo_name != "gj" and n > 64):
+        return None
+    nt = (n + 15) // 16
+    tiles = nt * nt if algo_name == "gj" else nt * (nt + 1) // 2
+    return 4 * nt * tiles * 2048
+
+
+def rooflines(algo_name, n, batch, kern_ms):
+    """(binding roofline dict, the other one or None): HBM at 2 n^2 sizeof(T) algorithmic bytes per inversion, fp64 MFMA at
+    the flops above; the binding one is the one with the larger minimum time."""
+    bytes_per_inv = 2 * n * n * 8  # read A once + write A^-1 once (SURVEY.md 8d)
+    gbs = batch * bytes_per_inv / (kern_ms * 1e-3) / 1e9
+    hbm = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": batch * bytes_per_inv}
+    fl = mfma_flops_per_inversion(algo_name, n)
+    if fl is None:
+        return hbm, None
+    tf = batch * fl / (kern_ms * 1e-3) / 1e12
+    mf = {"bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
+          "algorithmic_flops_per_launch": batch * fl}
+    return (hbm, mf) if hbm["frac"] >= mf["frac"] else (mf, hbm)
 
 
 def load_traffic(kernel_name, n):
@@ -279,17 +307,21 @@ def main():
                 e_.record()
             torch.cuda.synchronize()
             ms2 = float(np.mean([s_.elapsed_time(e_) for s_, e_ in ev2]))
-            gbs = b2 * 2 * n2 * n2 * 8 / (ms2 * 1e-3) / 1e9
+            r1, r2 = rooflines(algo2_name, n2, b2, ms2)
             others[wname] = {"kernel": api.kernel_name(algo2, api.F64, n2), "batch": b2, "kernel_ms": ms2,
-                             "inversions_per_s": b2 / (ms2 * 1e-3), "GB_per_s": gbs, "frac": gbs / HBM_PEAK_GBS}
+                             "inversions_per_s": b2 / (ms2 * 1e-3), "bound": r1["bound"], "frac": r1["frac"],
+                             "achieved": r1["achieved"], "unit": r1["unit"],
+                             "other_bound_frac": None if r2 is None else r2["frac"]}
             del a2, x2
 
     if rank == 0:
         total = batch * world * args.steps
         value = total / elapsed
-        bytes_per_inv = 2 * n * n * 8  # read A once + write A^-1 once
-        achieved = batch * bytes_per_inv / (kern_ms * 1e-3) / 1e9
         kname = api.kernel_name(algo, api.F64, n, kernel)
+        roof, roof_other = rooflines(algo_name, n, batch, kern_ms)
+        roof.update({"traffic": load_traffic(kname, n), "kernel": kname, "kernel_ms": kern_ms})
+        if roof_other is not None:
+            roof["other_bound"] = roof_other
         out = {
             "metric": "matrix inversions/s", "value": value, "unit": "inversions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -297,9 +329,7 @@ def main():
             "config": {"workload": f"{args.workload}: {desc.replace('batch', str(batch))}", "n": n,
                        "batch_per_gpu": batch, "algorithm": algo_name, "kernel": kname,
                        "sharding": f"batch block-partitioned over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kname, n),
-                         "kernel": kname, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": batch * bytes_per_inv},
+            "roofline": roof,
         }
         if gather_ms is not None:
             out["allgather_ms"] = gather_ms
