@@ -286,6 +286,17 @@ def main():
     resid = float((torch.bmm(am, xm) - torch.eye(n, dtype=a.dtype, device=device)).abs().max())
     assert resid < 1e-11 * n, f"residual {resid}"
 
+    # what a plain device-to-device copy of the same bytes reaches on this box (SURVEY 8d asks for the fraction against
+    # the measured copy bandwidth beside the nominal 8 TB/s); torch's copy kernel, same read+write byte count
+    copy_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    x.copy_(a)
+    for s_, e_ in copy_ev:
+        s_.record()
+        x.copy_(a)
+        e_.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2 * a.numel() * a.element_size() / (float(np.median([s_.elapsed_time(e_) for s_, e_ in copy_ev])) * 1e-3) / 1e9
+
     others = {}
     if rank == 0 and world == 1 and not args.no_others:
         # the other single-GPU configs of BASELINE.json, a few launches each (same timing method), for the record
@@ -320,6 +331,9 @@ def main():
         kname = api.kernel_name(algo, api.F64, n, kernel)
         roof, roof_other = rooflines(algo_name, n, batch, kern_ms)
         roof.update({"traffic": load_traffic(kname, n), "kernel": kname, "kernel_ms": kern_ms})
+        hbm_side = roof if roof["bound"] == "hbm" else roof_other
+        hbm_side["measured_copy_GBs"] = copy_gbs
+        hbm_side["frac_of_measured_copy"] = hbm_side["achieved"] / copy_gbs
         if roof_other is not None:
             roof["other_bound"] = roof_other
         out = {

@@ -498,6 +498,29 @@ def test_full_size_properties(n, batch, algo):
     assert rel_err(xm[idx].reshape(-1).cpu().numpy(), want, n) < 1e-10
 
 
+@pytest.mark.parametrize("n,batch", [(8, 1003), (16, 1001), (32, 517), (64, 300), (100, 67), (128, 41), (200, 9)])
+def test_sharded_results_bit_identical_to_unsharded(n, batch):
+    """SURVEY 8(e) determinism: what rank g of G computes for its block of the batch is bit-identical to the same
+    matrices inverted in one launch (no atomics, no dependence on the position inside a wavefront or workgroup), for the
+    inversion (both algorithms) and the fused pipeline, G = 1 vs 2, 3, 8 with ragged tails."""
+    shard = pkg("shard")
+    a = dev(spd_batch(n, batch, seed=900 + n))
+    rng = np.random.default_rng(n)
+    va, vc, vd = (dev(rng.random(batch * n)) for _ in range(3))
+    full = {algo: api.inverse_batched(a, n, algo, batch=batch).clone() for algo in (GJ, CH)}
+    full_m = api.calcluateMean(n, va, a, vc, vd).clone()
+    for world in (2, 3, 8):
+        parts = shard.partition(batch, world, shard.packing_multiple(n))
+        assert parts[0][0] == 0 and max(hi for _, hi in parts) == batch
+        for algo in (GJ, CH):
+            got = torch.cat([api.inverse_batched(a[lo * n * n:hi * n * n], n, algo, batch=hi - lo)
+                             for lo, hi in parts if hi > lo])
+            assert torch.equal(got, full[algo]), (n, world, algo)
+        got_m = torch.cat([api.calcluateMean(n, va[lo * n:hi * n], a[lo * n * n:hi * n * n], vc[lo * n:hi * n],
+                                             vd[lo * n:hi * n], batchSize=hi - lo) for lo, hi in parts if hi > lo])
+        assert torch.equal(got_m, full_m), (n, world)
+
+
 def test_batch_beyond_32bit_element_offsets():
     """BASELINE configs[3] (1 M x 64x64 fp64) on one GPU, slightly enlarged so that ELEMENT offsets exceed 2^32 (the
     reference indexes with int, src/gauss/batched_invert.cu:130, and overflows at 2^31). 36 GB per operand."""
