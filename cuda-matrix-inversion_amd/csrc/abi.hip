@@ -99,7 +99,7 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
     case MATINV_KERNEL_TILE:
         if (algo == MATINV_ALGO_CHOLESKY) {
             if (!spd_tile_supports<T>(n) || chol_phases != 7)
-                return fail(MATINV_ERR_UNSUPPORTED, "tile family serves the full f64 SPD inverse with n <= 64 only (n=%d)", n);
+                return fail(MATINV_ERR_UNSUPPORTED, "tile family serves the full SPD inverse with n <= 128 (f64) / 64 (f32) only (n=%d)", n);
             e = launch_spd_tile<T>(n, A, X, batch, dInfo, stream);
             break;
         }

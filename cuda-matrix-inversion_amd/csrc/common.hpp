@@ -102,6 +102,10 @@ bool tile4_supports_f64(int n);
 hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
                                hipStream_t stream);
 const char *name_gj_tile4_f64(int n);
+// the same kernel as the Cholesky entry point for 64 < n <= 128 (lower triangle only, positivity-checked pivots)
+hipError_t launch_spd_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
+                                hipStream_t stream);
+const char *name_spd_tile4_f64(int n);
 // SPD (symmetric blocked sweep) on the tile layout, f64, n <= 64
 template <class T>
 hipError_t launch_spd_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);

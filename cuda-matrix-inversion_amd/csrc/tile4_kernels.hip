@@ -23,7 +23,11 @@ namespace matinv {
 // NT = tiles per dimension, T4_WAVES = wavefronts per matrix, NC = tile columns per wave = ceil(NT / T4_WAVES).
 // (Measured and not used: NT = 4 with 2 waves per 64 x 64 matrix, 142 VGPRs, 3 waves per SIMD: 4.7e7 inv/s against 6.1e7
 // for the one-wave kernel of tile_kernels.hip -- the redundant panel solve and the barriers cost more than the occupancy buys.)
-template <int NT, bool FULL, int T4_WAVES = 4>
+// SPD = the Cholesky entry point for 64 < n <= 128: the same sweep, but only the LOWER triangle of A is read (the upper
+// tiles are mirrored while loading, as the Cholesky contract demands -- include/matinv.h), the natural pivots are accepted
+// when they are all POSITIVE (leading principal minors of a symmetric matrix: positive definite; no multiplier test, the
+// sweep is stable on SPD input), and rejected matrices go to the LDS Cholesky, which reports the failing column.
+template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
 __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
                                                                        int *info, int n_rt, unsigned batch,
                                                                        int *work_count, int *work_list)
@@ -55,7 +59,10 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void
                     const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
                     const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
                     const bool in = (tj < NT) && (FULL || (row < n && col < n));
-                    acc[ti][jl][r] = in ? A[uoff + lane_off] : ((row == col) ? 1.0 : 0.0);
+                    // W = A^T: W[row][col] = A[col][row] at col*... the batch is column-major, so uoff + lane_off addresses
+                    // A(col, row); its mirror A(row, col) sits at col * n + row
+                    const bool mirror = SPD && (col < row);  // A(col,row) with col < row is an UPPER element: read A(row,col)
+                    acc[ti][jl][r] = in ? (mirror ? A[(unsigned)(col * n + row)] : A[uoff + lane_off]) : ((row == col) ? 1.0 : 0.0);
                 }
             }
         unsigned long long bad = 0;
@@ -77,7 +84,11 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void
         };
         stage_panel(0);
         __syncthreads();
-        panel_solve<NT>(panel, 0, q, c, aop, bad);
+        {
+            PanelSolve<NT, SPD> ps0;
+#pragma unroll
+            for (int s0 = 0; s0 < PanelSolve<NT, SPD>::NSTAGE; ++s0) ps0.stage(s0, panel, 0, q, c, aop, bad);
+        }
 
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -90,11 +101,28 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void
             for (int jl = 0; jl < NC; ++jl) bop[jl] = acc[tK][jl][rK];
             if (w == owner) bop[jo] = panel_lane ? (diag_lane ? 1.0 : 0.0) : bop[jo];
             // C operand: zero on the pivot columns (owner) and on the pivot rows (everyone)
-            if (w == owner) {
+            // One asm block per tile row, EXEC narrowed to the owner's pivot-column lanes and the block skipped when that is
+            // empty (every other wave): written as a C++ select hipcc emits 64 v_cndmask per step in EVERY wave (146 of
+            // ~250 VALU instructions per step; fp64 VALU and MFMA do not overlap on gfx950, so they cost), and with a
+            // scalar branch it merges the two paths with 32 register copies and twice the registers.
+            {
+                const unsigned long long zmask = __ballot((w == owner) && panel_lane);
 #pragma unroll
-                for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[ti][jo][r] = panel_lane ? 0.0 : acc[ti][jo][r];
+                for (int ti = 0; ti < NT; ++ti) {
+                    unsigned long long save;
+                    asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
+                                 "s_cbranch_execz 1f\n\t"
+                                 "v_mov_b64_e32 %0, 0\n\t"
+                                 "v_mov_b64_e32 %1, 0\n\t"
+                                 "v_mov_b64_e32 %2, 0\n\t"
+                                 "v_mov_b64_e32 %3, 0\n"
+                                 "1:\n\t"
+                                 "s_mov_b64 exec, %[save]"
+                                 : "+v"(acc[ti][jo][0]), "+v"(acc[ti][jo][1]), "+v"(acc[ti][jo][2]), "+v"(acc[ti][jo][3]),
+                                   [save] "=&s"(save)
+                                 : [mask] "s"(zmask)
+                                 : "scc");
+                }
             }
 #pragma unroll
             for (int jl = 0; jl < NC; ++jl) acc[tK][jl][rK] = 0.0;
@@ -109,10 +137,10 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void
                 __syncthreads();
 #endif
                 const double *pnext = panel + ((kb + 1) & 1) * (N * 4);
-                constexpr int NS = PanelSolve<NT>::NSTAGE;
+                constexpr int NS = PanelSolve<NT, SPD>::NSTAGE;
                 constexpr int NB = NT * (NC - 1);
                 double aop_next[NT];
-                PanelSolve<NT> ps;
+                PanelSolve<NT, SPD> ps;
                 int count = 0, ev = 0;
                 auto run_events = [&](bool flush) {
 #pragma unroll
@@ -179,8 +207,9 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void
 bool tile4_supports_f64(int n) { return n > 64 && n <= 128; }
 
 
-hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
-                               hipStream_t stream)
+template <bool SPD>
+static hipError_t launch_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
+                                   hipStream_t stream)
 {
     if (!tile4_supports_f64(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
@@ -194,9 +223,9 @@ hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double>
     const unsigned b = (unsigned)batch;
 #define T4_LAUNCH(NT_)                                                                                                \
     if (n == 16 * NT_)                                                                                                \
-        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
+        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true, 4, SPD>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
     else                                                                                                              \
-        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1)
+        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, 4, SPD>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1)
     switch (nt) {
     case 5: T4_LAUNCH(5); break;
     case 6: T4_LAUNCH(6); break;
@@ -205,9 +234,33 @@ hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double>
     }
 #undef T4_LAUNCH
     e = hipGetLastError();
-    if (e == hipSuccess) e = launch_gj_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream);
+    if (e == hipSuccess)
+        e = SPD ? launch_chol_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream)
+                : launch_gj_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
+}
+
+hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
+                               hipStream_t stream)
+{
+    return launch_tile4_f64<false>(n, A, X, batch, info, stream);
+}
+hipError_t launch_spd_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
+                                hipStream_t stream)
+{
+    return launch_tile4_f64<true>(n, A, X, batch, info, stream);
+}
+
+const char *name_spd_tile4_f64(int n)
+{
+    const bool full = (n % 16) == 0;
+    switch ((n + 15) / 16) {
+    case 5: return full ? "matinv_gj_tile4_f64<5, true, 4, true>" : "matinv_gj_tile4_f64<5, false, 4, true>";
+    case 6: return full ? "matinv_gj_tile4_f64<6, true, 4, true>" : "matinv_gj_tile4_f64<6, false, 4, true>";
+    case 7: return full ? "matinv_gj_tile4_f64<7, true, 4, true>" : "matinv_gj_tile4_f64<7, false, 4, true>";
+    default: return full ? "matinv_gj_tile4_f64<8, true, 4, true>" : "matinv_gj_tile4_f64<8, false, 4, true>";
+    }
 }
 
 const char *name_gj_tile4_f64(int n)

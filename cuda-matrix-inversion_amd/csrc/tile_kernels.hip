@@ -583,7 +583,7 @@ hipError_t launch_gj_tile<double>(int n, BatchRef<const double> A, BatchRef<doub
 template <class T>
 bool spd_tile_supports(int n);
 template <>
-bool spd_tile_supports<double>(int n) { return n >= 1 && n <= 64; }
+bool spd_tile_supports<double>(int n) { return n >= 1 && n <= 128; }  // 64 < n <= 128: tile4_kernels.hip
 template <>
 bool spd_tile_supports<float>(int n) { return n >= 1 && n <= 64; }
 
@@ -626,6 +626,7 @@ hipError_t launch_spd_tile<double>(int n, BatchRef<const double> A, BatchRef<dou
                                    hipStream_t stream)
 {
     if (!spd_tile_supports<double>(n)) return hipErrorInvalidValue;
+    if (n > 64) return launch_spd_tile4_f64(n, A, X, batch, info, stream);
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -664,6 +665,7 @@ const char *name_spd_tile(bool f64, int n)
         default: return full ? "matinv_spd_tile_f32<4, true>" : "matinv_spd_tile_f32<4, false>";
         }
     }
+    if (n > 64) return name_spd_tile4_f64(n);
     switch ((n + 15) / 16) {
     case 1: return full ? "matinv_spd_tile_f64<1, true>" : "matinv_spd_tile_f64<1, false>";
     case 2: return full ? "matinv_spd_tile_f64<2, true>" : "matinv_spd_tile_f64<2, false>";

@@ -96,7 +96,7 @@ def test_cholesky_spd_fp64_vs_oracle(n, family):
     assert np.array_equal(g, g.transpose(0, 2, 1)) or rel_err(g.transpose(0, 2, 1).reshape(-1), got, n) < 1e-14
 
 
-@pytest.mark.parametrize("n", [5, 16, 33, 64])
+@pytest.mark.parametrize("n", [5, 16, 33, 64, 70, 96, 128])
 def test_cholesky_reads_only_the_lower_triangle(n):
     """Garbage in the strict upper triangle must not change the result (both Cholesky families)."""
     a = spd_batch(n, 9, seed=7 + n).reshape(9, n, n)      # memory [k, col, row]
@@ -111,7 +111,7 @@ def test_cholesky_reads_only_the_lower_triangle(n):
         assert rel_err(got, want, n) < 1e-10, fam
 
 
-@pytest.mark.parametrize("n", [8, 32, 64])
+@pytest.mark.parametrize("n", [8, 32, 64, 100, 128])
 def test_spd_general_not_diagonally_dominant(n):
     """SPD but far from diagonally dominant (Wishart-like G G^T + eps I, cond ~1e3-1e5): no pivoting needed or wanted."""
     rng = np.random.default_rng(n)
@@ -159,7 +159,7 @@ def test_simplemean_cholesky_golden(gold):
     assert rel_err(got, gold["simpleMean/chol"], n) < 1e-9  # cond ~1185
 
 
-@pytest.mark.parametrize("n", [3, 8, 16, 32, 64])
+@pytest.mark.parametrize("n", [3, 8, 16, 32, 64, 90, 128])
 def test_singular_and_not_spd_report_info(n):
     a = spd_batch(n, 8, seed=3).reshape(8, n, n)
     # structurally singular inputs are detected exactly by every kernel family (an exactly zero column stays
