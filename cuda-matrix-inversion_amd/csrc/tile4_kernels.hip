@@ -28,14 +28,13 @@ namespace matinv {
 // when they are all POSITIVE (leading principal minors of a symmetric matrix: positive definite; no multiplier test, the
 // sweep is stable on SPD input), and rejected matrices go to the LDS Cholesky, which reports the failing column.
 template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
-__global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
+__global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
                                                                        int *info, int n_rt, unsigned batch,
                                                                        int *work_count, int *work_list)
 {
     constexpr int N = 16 * NT;
     constexpr int NKB = 4 * NT;
     constexpr int NC = (NT + T4_WAVES - 1) / T4_WAVES;
-    const int n = FULL ? N : n_rt;
     __shared__ __attribute__((aligned(16))) double panel[2 * N * 4];  // double buffered [row][4 pivot columns]
     const int l = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;  // wave-uniform
@@ -43,6 +42,10 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
         const double *A = Ain.at_uniform(mat);
         double *X = Xout.at_uniform(mat);
+        // run-time n made opaque once per matrix: keeps LICM from hoisting the tile offsets and bounds predicates of the
+        // load and store loops out of the batch loop (370-510 VGPRs otherwise)
+        int n = FULL ? N : n_rt;
+        if (!FULL) asm volatile("" : "+s"(n));
         int q = l >> 4, c = l & 15;
         const unsigned lane_off = (unsigned)((l >> 4) * n + (l & 15));
         asm volatile("" : "+v"(q), "+v"(c));  // keep LICM from hoisting ~100 per-lane constants (see tile_kernels.hip)
@@ -58,7 +61,9 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
                     const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
-                    const bool in = (tj < NT) && (FULL || (row < n && col < n));
+                    // only the last tile row / a wave's last tile column can reach beyond n: interior tiles skip the test
+                    const bool edge = !FULL && (ti == NT - 1 || jl == NC - 1);
+                    const bool in = (tj < NT) && (!edge || (row < n && col < n));
                     // W = A^T: W[row][col] = A[col][row] at col*... the batch is column-major, so uoff + lane_off addresses
                     // A(col, row); its mirror A(row, col) sits at col * n + row
                     const bool mirror = SPD && (col < row);  // A(col,row) with col < row is an UPPER element: read A(row,col)
@@ -192,7 +197,8 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : (FULL ? 2 : 1)) void
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
                         const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
-                        if ((tj < NT) && (FULL || (row < n && col < n))) X[uoff + lane_off] = acc[ti][jl][r];
+                        const bool edge = !FULL && (ti == NT - 1 || jl == NC - 1);
+                        if ((tj < NT) && (!edge || (row < n && col < n))) X[uoff + lane_off] = acc[ti][jl][r];
                     }
                 }
             if (info && threadIdx.x == 0) info[mat] = 0;

@@ -94,12 +94,15 @@ __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> 
     // 16-byte access feeds two tiles and a 16-lane group covers 256 contiguous bytes. Nothing else in the kernel
     // depends on the relabelling (a symmetric permutation of the matrix: inv(P A P^T) = P inv(A) P^T).
     constexpr bool PAIRED = FULL && (NT % 2 == 0);
-    const int n = FULL ? N : n_rt;
     const int l = threadIdx.x;
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
         const T *A = Ain.at_uniform(mat);
         T *X = Xout.at_uniform(mat);
+        // run-time n: made opaque once per matrix, otherwise LICM hoists the 16 NT^2 tile offsets (products with n) and
+        // the bounds predicates of both the load and the store loop out of this loop (370-510 VGPRs, one wave per SIMD)
+        int n = FULL ? N : n_rt;
+        if (!FULL) asm volatile("" : "+s"(n));
         // Launder the lane coordinates once per matrix: otherwise LICM hoists the ~60 per-lane constants of the 4*NT
         // unrolled block steps (I_4 lanes, e_q entries, lane masks) out of this loop and the allocator spills them.
         int q = l >> 4, c = l & 15;
@@ -131,9 +134,11 @@ __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
-                        // identity padding beyond n: blockdiag(A, I)^-1 = blockdiag(A^-1, I)
+                        // identity padding beyond n: blockdiag(A, I)^-1 = blockdiag(A^-1, I). Only the last tile row and
+                        // column can reach beyond n (n > 16 (NT - 1)): the interior tiles load without a predicate.
                         const unsigned uoff = (unsigned)((16 * ti + G::trow(r, 0)) * n + 16 * tj);
-                        acc[ti][tj][r] = (FULL || (row < n && col < n)) ? A[uoff + lane_off] : ((row == col) ? (T)1 : (T)0);
+                        const bool edge = !FULL && (ti == NT - 1 || tj == NT - 1);
+                        acc[ti][tj][r] = (!edge || (row < n && col < n)) ? A[uoff + lane_off] : ((row == col) ? (T)1 : (T)0);
                     }
         }
         unsigned long long bad = 0;  // wave-uniform: lanes that saw a multiplier above TAU (or NaN)
@@ -263,7 +268,8 @@ __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> 
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
                             const unsigned uoff = (unsigned)((16 * ti + G::trow(r, 0)) * n + 16 * tj);
-                            if (FULL || (row < n && col < n)) X[uoff + lane_off] = acc[ti][tj][r];
+                            const bool edge = !FULL && (ti == NT - 1 || tj == NT - 1);
+                            if (!edge || (row < n && col < n)) X[uoff + lane_off] = acc[ti][tj][r];
                         }
             }
             if (info && l == 0) info[mat] = 0;
@@ -280,7 +286,7 @@ __device__ __forceinline__ void gj_tile_body(BatchRef<const T> Ain, BatchRef<T> 
 // LOOKAHEAD: software pipelining across block steps -- the tile column that holds the NEXT pivot columns is updated
 // first, the next panel is extracted and solved while the remaining MFMAs of the current step are in flight.
 template <int NT, bool FULL, bool LOOKAHEAD>
-__global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f64(BatchRef<const double> Ain,
+__global__ __launch_bounds__(64, 2) void matinv_gj_tile_f64(BatchRef<const double> Ain,
                                                                                  BatchRef<double> Xout, int *info,
                                                                                  int n_rt, unsigned batch,
                                                                                  int *work_count, int *work_list)
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(64, (FULL || NT < 3) ? 2 : 1) void matinv_gj_tile_f
 // fp32 (the reference's DataType): v_mfma_f32_16x16x4_f32, 4 VGPRs per tile (64 at n = 64), same algorithm; the pivot
 // blocks follow the f32 accumulator layout (TileGeo<float>).
 template <int NT, bool FULL, bool LOOKAHEAD>
-__global__ __launch_bounds__(64, 4) void matinv_gj_tile_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
+__global__ __launch_bounds__(64, FULL ? 4 : 3) void matinv_gj_tile_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
                                                            int n_rt, unsigned batch, int *work_count, int *work_list)
 {
     __shared__ __attribute__((aligned(16))) float panel[16 * NT * 4];
@@ -525,7 +531,7 @@ hipError_t launch_gj_tile<float>(int n, BatchRef<const float> A, BatchRef<float>
     if (n == 16 * NT_)                                                                                                \
         hipLaunchKernelGGL((matinv_gj_tile_f32<NT_, true, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
     else                                                                                                              \
-        hipLaunchKernelGGL((matinv_gj_tile_f32<NT_, false, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1)
+        hipLaunchKernelGGL((matinv_gj_tile_f32<NT_, false, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1)
     switch (nt) {
     case 1: TILE_LAUNCH_F32(1); break;
     case 2: TILE_LAUNCH_F32(2); break;
@@ -565,6 +571,8 @@ hipError_t launch_gj_tile<double>(int n, BatchRef<const double> A, BatchRef<doub
         hipLaunchKernelGGL((matinv_gj_tile_f64<NT_, true, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
     else if (n == 16 * NT_)                                                                                           \
         hipLaunchKernelGGL((matinv_gj_tile_f64<NT_, true, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    else if (lookahead)                                                                                               \
+        hipLaunchKernelGGL((matinv_gj_tile_f64<NT_, false, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
     else                                                                                                              \
         hipLaunchKernelGGL((matinv_gj_tile_f64<NT_, false, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1)
     switch (nt) {
@@ -679,19 +687,19 @@ const char *name_gj_tile(bool f64, int n)
     if (!f64) {
         const bool fullf = (n % 16) == 0;
         switch ((n + 15) / 16) {
-        case 1: return fullf ? "matinv_gj_tile_f32<1, true, true>" : "matinv_gj_tile_f32<1, false, false>";
-        case 2: return fullf ? "matinv_gj_tile_f32<2, true, true>" : "matinv_gj_tile_f32<2, false, false>";
-        case 3: return fullf ? "matinv_gj_tile_f32<3, true, true>" : "matinv_gj_tile_f32<3, false, false>";
-        default: return fullf ? "matinv_gj_tile_f32<4, true, true>" : "matinv_gj_tile_f32<4, false, false>";
+        case 1: return fullf ? "matinv_gj_tile_f32<1, true, true>" : "matinv_gj_tile_f32<1, false, true>";
+        case 2: return fullf ? "matinv_gj_tile_f32<2, true, true>" : "matinv_gj_tile_f32<2, false, true>";
+        case 3: return fullf ? "matinv_gj_tile_f32<3, true, true>" : "matinv_gj_tile_f32<3, false, true>";
+        default: return fullf ? "matinv_gj_tile_f32<4, true, true>" : "matinv_gj_tile_f32<4, false, true>";
         }
     }
     if (n > 64) return name_gj_tile4_f64(n);
     const bool full = (n % 16) == 0;
     switch ((n + 15) / 16) {
-    case 1: return full ? "matinv_gj_tile_f64<1, true, true>" : "matinv_gj_tile_f64<1, false, false>";
-    case 2: return full ? "matinv_gj_tile_f64<2, true, true>" : "matinv_gj_tile_f64<2, false, false>";
-    case 3: return full ? "matinv_gj_tile_f64<3, true, true>" : "matinv_gj_tile_f64<3, false, false>";
-    default: return full ? "matinv_gj_tile_f64<4, true, true>" : "matinv_gj_tile_f64<4, false, false>";
+    case 1: return full ? "matinv_gj_tile_f64<1, true, true>" : "matinv_gj_tile_f64<1, false, true>";
+    case 2: return full ? "matinv_gj_tile_f64<2, true, true>" : "matinv_gj_tile_f64<2, false, true>";
+    case 3: return full ? "matinv_gj_tile_f64<3, true, true>" : "matinv_gj_tile_f64<3, false, true>";
+    default: return full ? "matinv_gj_tile_f64<4, true, true>" : "matinv_gj_tile_f64<4, false, true>";
     }
 }
 
