@@ -97,15 +97,14 @@ template <class T>
 hipError_t launch_gj_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 template <class T>
 bool tile_family_supports(int n);
-// four-wave variant of the tile family, f64, 64 < n <= 128 (tile4_kernels.hip)
-bool tile4_supports_f64(int n);
-hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
-                               hipStream_t stream);
-const char *name_gj_tile4_f64(int n);
-// the same kernel as the Cholesky entry point for 64 < n <= 128 (lower triangle only, positivity-checked pivots)
-hipError_t launch_spd_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
-                                hipStream_t stream);
-const char *name_spd_tile4_f64(int n);
+// four-wave variant of the tile family, 64 < n <= 128, f64 and f32 (tile4_kernels.hip); the spd entry is the same
+// kernel with lower-triangle loads and positivity-checked pivots (the Cholesky contract)
+bool tile4_supports(int n);
+template <class T>
+hipError_t launch_gj_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+hipError_t launch_spd_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+const char *name_tile4(bool f64, bool spd, int n);
 // SPD (symmetric blocked sweep) on the tile layout, f64, n <= 64
 template <class T>
 hipError_t launch_spd_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);

@@ -15,6 +15,8 @@
 // which handles n <= 141.
 //
 // Replaces, for 64 < n <= 128, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95.
+#include <cstdio>
+
 #include "tile_common.hpp"
 
 namespace matinv {
@@ -27,31 +29,31 @@ namespace matinv {
 // tiles are mirrored while loading, as the Cholesky contract demands -- include/matinv.h), the natural pivots are accepted
 // when they are all POSITIVE (leading principal minors of a symmetric matrix: positive definite; no multiplier test, the
 // sweep is stable on SPD input), and rejected matrices go to the LDS Cholesky, which reports the failing column.
-template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
-__global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
-                                                                       int *info, int n_rt, unsigned batch,
-                                                                       int *work_count, int *work_list)
+template <class T, int NT, bool FULL, int T4_WAVES, bool SPD>
+__device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
+                                              int *work_count, int *work_list, T *panel)
 {
+    typedef TileGeo<T> G;
+    typedef typename G::vec4 vec4;
     constexpr int N = 16 * NT;
     constexpr int NKB = 4 * NT;
     constexpr int NC = (NT + T4_WAVES - 1) / T4_WAVES;
-    __shared__ __attribute__((aligned(16))) double panel[2 * N * 4];  // double buffered [row][4 pivot columns]
     const int l = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;  // wave-uniform
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
-        const double *A = Ain.at_uniform(mat);
-        double *X = Xout.at_uniform(mat);
+        const T *A = Ain.at_uniform(mat);
+        T *X = Xout.at_uniform(mat);
         // run-time n made opaque once per matrix: keeps LICM from hoisting the tile offsets and bounds predicates of the
         // load and store loops out of the batch loop (370-510 VGPRs otherwise)
         int n = FULL ? N : n_rt;
         if (!FULL) asm volatile("" : "+s"(n));
         int q = l >> 4, c = l & 15;
-        const unsigned lane_off = (unsigned)((l >> 4) * n + (l & 15));
+        const unsigned lane_off = (unsigned)(G::trow(0, l >> 4) * n + (l & 15));
         asm volatile("" : "+v"(q), "+v"(c));  // keep LICM from hoisting ~100 per-lane constants (see tile_kernels.hip)
 
         // acc[ti][jl] = tile (ti, w + 4*jl); W = A^T as in the single-wave kernel
-        v4d acc[NT][NC];
+        vec4 acc[NT][NC];
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -59,52 +61,52 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_ti
                 const int tj = w + T4_WAVES * jl;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
-                    const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
+                    const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
+                    const unsigned uoff = (unsigned)((16 * ti + G::trow(r, 0)) * n + 16 * tj);
                     // only the last tile row / a wave's last tile column can reach beyond n: interior tiles skip the test
                     const bool edge = !FULL && (ti == NT - 1 || jl == NC - 1);
                     const bool in = (tj < NT) && (!edge || (row < n && col < n));
                     // W = A^T: W[row][col] = A[col][row] at col*... the batch is column-major, so uoff + lane_off addresses
                     // A(col, row); its mirror A(row, col) sits at col * n + row
                     const bool mirror = SPD && (col < row);  // A(col,row) with col < row is an UPPER element: read A(row,col)
-                    acc[ti][jl][r] = in ? (mirror ? A[(unsigned)(col * n + row)] : A[uoff + lane_off]) : ((row == col) ? 1.0 : 0.0);
+                    acc[ti][jl][r] = in ? (mirror ? A[(unsigned)(col * n + row)] : A[uoff + lane_off]) : ((row == col) ? (T)1 : (T)0);
                 }
             }
         unsigned long long bad = 0;
-        double aop[NT], bop[NC];
+        T aop[NT], bop[NC];
 
         // Look-ahead pipeline with ONE workgroup barrier per block step (the panel is double buffered in LDS):
         //   every wave updates its local column jo_n first (for the next owner that is the column holding the next
         //   pivot columns); the next owner stages them; barrier; the other local column is updated while every wave
         //   solves the next panel (MFMAs pinned between the solve stages).
         auto stage_panel = [&](int kb) {
-            const int tK = kb >> 2, c0 = 4 * (kb & 3), jo = tK / T4_WAVES;
-            double *buf = panel + (kb & 1) * (N * 4);
-            if (w == tK % T4_WAVES && c >= c0 && c < c0 + 4) {
+            const int tK = kb >> 2, rK = kb & 3, jo = tK / T4_WAVES;
+            T *buf = panel + (kb & 1) * (N * 4);
+            if (w == tK % T4_WAVES && G::blk(c) == rK) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) buf[(16 * ti + 4 * r + q) * 4 + (c - c0)] = acc[ti][jo][r];
+                    for (int r = 0; r < 4; ++r) buf[(16 * ti + G::trow(r, q)) * 4 + G::piv(c)] = acc[ti][jo][r];
             }
         };
         stage_panel(0);
         __syncthreads();
         {
-            PanelSolve<NT, SPD> ps0;
+            PanelSolve<NT, SPD, T> ps0;
 #pragma unroll
-            for (int s0 = 0; s0 < PanelSolve<NT, SPD>::NSTAGE; ++s0) ps0.stage(s0, panel, 0, q, c, aop, bad);
+            for (int s0 = 0; s0 < PanelSolve<NT, SPD, T>::NSTAGE; ++s0) ps0.stage(s0, panel, 0, q, c, aop, bad);
         }
 
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const int tK = kb >> 2, rK = kb & 3, c0 = 4 * (kb & 3);
+            const int tK = kb >> 2, rK = kb & 3;
             const int owner = tK % T4_WAVES, jo = tK / T4_WAVES;  // wave and local column holding the pivot columns
-            const bool panel_lane = (c >= c0) && (c < c0 + 4);
-            const bool diag_lane = panel_lane && (c - c0 == q);
+            const bool panel_lane = G::blk(c) == rK;
+            const bool diag_lane = panel_lane && (G::piv(c) == q);
             // B operand: pivot rows of the wave's own columns; I_4 on the pivot columns (owner only)
 #pragma unroll
             for (int jl = 0; jl < NC; ++jl) bop[jl] = acc[tK][jl][rK];
-            if (w == owner) bop[jo] = panel_lane ? (diag_lane ? 1.0 : 0.0) : bop[jo];
+            if (w == owner) bop[jo] = panel_lane ? (diag_lane ? (T)1 : (T)0) : bop[jo];
             // C operand: zero on the pivot columns (owner) and on the pivot rows (everyone)
             // One asm block per tile row, EXEC narrowed to the owner's pivot-column lanes and the block skipped when that is
             // empty (every other wave): written as a C++ select hipcc emits 64 v_cndmask per step in EVERY wave (146 of
@@ -115,37 +117,51 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_ti
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti) {
                     unsigned long long save;
-                    asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
-                                 "s_cbranch_execz 1f\n\t"
-                                 "v_mov_b64_e32 %0, 0\n\t"
-                                 "v_mov_b64_e32 %1, 0\n\t"
-                                 "v_mov_b64_e32 %2, 0\n\t"
-                                 "v_mov_b64_e32 %3, 0\n"
-                                 "1:\n\t"
-                                 "s_mov_b64 exec, %[save]"
-                                 : "+v"(acc[ti][jo][0]), "+v"(acc[ti][jo][1]), "+v"(acc[ti][jo][2]), "+v"(acc[ti][jo][3]),
-                                   [save] "=&s"(save)
-                                 : [mask] "s"(zmask)
-                                 : "scc");
+                    if constexpr (sizeof(T) == 8)
+                        asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
+                                     "s_cbranch_execz 1f\n\t"
+                                     "v_mov_b64_e32 %0, 0\n\t"
+                                     "v_mov_b64_e32 %1, 0\n\t"
+                                     "v_mov_b64_e32 %2, 0\n\t"
+                                     "v_mov_b64_e32 %3, 0\n"
+                                     "1:\n\t"
+                                     "s_mov_b64 exec, %[save]"
+                                     : "+v"(acc[ti][jo][0]), "+v"(acc[ti][jo][1]), "+v"(acc[ti][jo][2]), "+v"(acc[ti][jo][3]),
+                                       [save] "=&s"(save)
+                                     : [mask] "s"(zmask)
+                                     : "scc");
+                    else
+                        asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
+                                     "s_cbranch_execz 1f\n\t"
+                                     "v_mov_b32_e32 %0, 0\n\t"
+                                     "v_mov_b32_e32 %1, 0\n\t"
+                                     "v_mov_b32_e32 %2, 0\n\t"
+                                     "v_mov_b32_e32 %3, 0\n"
+                                     "1:\n\t"
+                                     "s_mov_b64 exec, %[save]"
+                                     : "+v"(acc[ti][jo][0]), "+v"(acc[ti][jo][1]), "+v"(acc[ti][jo][2]), "+v"(acc[ti][jo][3]),
+                                       [save] "=&s"(save)
+                                     : [mask] "s"(zmask)
+                                     : "scc");
                 }
             }
 #pragma unroll
-            for (int jl = 0; jl < NC; ++jl) acc[tK][jl][rK] = 0.0;
+            for (int jl = 0; jl < NC; ++jl) acc[tK][jl][rK] = (T)0;
 
             if (kb + 1 < NKB) {
                 const int jn = ((kb + 1) >> 2) / T4_WAVES;  // local column updated first
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
-                    acc[ti][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[jn], acc[ti][jn], 0, 0, 0);
+                    acc[ti][jn] = G::mfma(aop[ti], bop[jn], acc[ti][jn]);
                 stage_panel(kb + 1);
 #ifndef TILE_DBG_NO_BARRIER
                 __syncthreads();
 #endif
-                const double *pnext = panel + ((kb + 1) & 1) * (N * 4);
-                constexpr int NS = PanelSolve<NT, SPD>::NSTAGE;
+                const T *pnext = panel + ((kb + 1) & 1) * (N * 4);
+                constexpr int NS = PanelSolve<NT, SPD, T>::NSTAGE;
                 constexpr int NB = NT * (NC - 1);
-                double aop_next[NT];
-                PanelSolve<NT, SPD> ps;
+                T aop_next[NT];
+                PanelSolve<NT, SPD, T> ps;
                 int count = 0, ev = 0;
                 auto run_events = [&](bool flush) {
 #pragma unroll
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_ti
 #ifndef TILE_DBG_NO_PANEL
                             ps.stage(e, pnext, kb + 1, q, c, aop_next, bad);
 #else
-                            if (e >= 6) aop_next[e - 6] = aop[e - 6] * 0.5 + pnext[(16 * (e - 6) + c) * 4];
+                            if (e >= 6) aop_next[e - 6] = aop[e - 6] * (T)0.5 + pnext[(16 * (e - 6) + c) * 4];
 #endif
                             __builtin_amdgcn_sched_barrier(0);
                             ++ev;
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_ti
                     if (jl == jn) continue;
 #pragma unroll
                     for (int ti = 0; ti < NT; ++ti) {
-                        acc[ti][jl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[jl], acc[ti][jl], 0, 0, 0);
+                        acc[ti][jl] = G::mfma(aop[ti], bop[jl], acc[ti][jl]);
                         ++count;
                         run_events(false);
                     }
@@ -182,7 +198,7 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_ti
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                     for (int jl = 0; jl < NC; ++jl)
-                        acc[ti][jl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[jl], acc[ti][jl], 0, 0, 0);
+                        acc[ti][jl] = G::mfma(aop[ti], bop[jl], acc[ti][jl]);
             }
         }
         __syncthreads();  // both panel buffers are free again before the next matrix stages its first panel
@@ -195,8 +211,8 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_ti
                     const int tj = w + T4_WAVES * jl;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
-                        const unsigned uoff = (unsigned)((16 * ti + 4 * r) * n + 16 * tj);
+                        const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
+                        const unsigned uoff = (unsigned)((16 * ti + G::trow(r, 0)) * n + 16 * tj);
                         const bool edge = !FULL && (ti == NT - 1 || jl == NC - 1);
                         if ((tj < NT) && (!edge || (row < n && col < n))) X[uoff + lane_off] = acc[ti][jl][r];
                     }
@@ -209,15 +225,31 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_ti
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-bool tile4_supports_f64(int n) { return n > 64 && n <= 128; }
-
-
-template <bool SPD>
-static hipError_t launch_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
-                                   hipStream_t stream)
+// SPD = the Cholesky entry point for 64 < n <= 128 (see gj_tile4_body).
+template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
+__global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
+                                                                       int *info, int n_rt, unsigned batch,
+                                                                       int *work_count, int *work_list)
 {
-    if (!tile4_supports_f64(n)) return hipErrorInvalidValue;
+    __shared__ __attribute__((aligned(16))) double panel[2 * 16 * NT * 4];  // double buffered [row][4 pivot columns]
+    gj_tile4_body<double, NT, FULL, T4_WAVES, SPD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
+}
+// fp32 (the reference's DataType; its benchmark sweep goes up to n = 128): 16 tiles x 4 VGPRs per wave
+template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
+__global__ __launch_bounds__(64 * T4_WAVES, 3) void matinv_gj_tile4_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
+                                                                       int n_rt, unsigned batch, int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) float panel[2 * 16 * NT * 4];
+    gj_tile4_body<float, NT, FULL, T4_WAVES, SPD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
+}
+
+// ------------------------------------------------------------------------------------------------
+bool tile4_supports(int n) { return n > 64 && n <= 128; }
+
+template <class T, bool SPD>
+static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    if (!tile4_supports(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -225,59 +257,56 @@ static hipError_t launch_tile4_f64(int n, BatchRef<const double> A, BatchRef<dou
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
     const int nt = (n + 15) / 16;
-    const unsigned grid = (unsigned)(batch < 256u * 2u * 4u ? batch : 256u * 2u * 4u);
+    const unsigned grid = (unsigned)(batch < 256u * 3u * 4u ? batch : 256u * 3u * 4u);
     const unsigned b = (unsigned)batch;
 #define T4_LAUNCH(NT_)                                                                                                \
-    if (n == 16 * NT_)                                                                                                \
-        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true, 4, SPD>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
-    else                                                                                                              \
-        hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, 4, SPD>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1)
+    if constexpr (sizeof(T) == 8) {                                                                                   \
+        if (n == 16 * NT_)                                                                                            \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true, 4, SPD>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, 4, SPD>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    } else {                                                                                                          \
+        if (n == 16 * NT_)                                                                                            \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, true, 4, SPD>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, 4, SPD>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    }
     switch (nt) {
-    case 5: T4_LAUNCH(5); break;
-    case 6: T4_LAUNCH(6); break;
-    case 7: T4_LAUNCH(7); break;
-    default: T4_LAUNCH(8); break;
+    case 5: T4_LAUNCH(5) break;
+    case 6: T4_LAUNCH(6) break;
+    case 7: T4_LAUNCH(7) break;
+    default: T4_LAUNCH(8) break;
     }
 #undef T4_LAUNCH
     e = hipGetLastError();
     if (e == hipSuccess)
-        e = SPD ? launch_chol_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream)
-                : launch_gj_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream);
+        e = SPD ? launch_chol_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream)
+                : launch_gj_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 
-hipError_t launch_gj_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
-                               hipStream_t stream)
+template <class T>
+hipError_t launch_gj_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
-    return launch_tile4_f64<false>(n, A, X, batch, info, stream);
+    return launch_tile4<T, false>(n, A, X, batch, info, stream);
 }
-hipError_t launch_spd_tile4_f64(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info,
-                                hipStream_t stream)
+template <class T>
+hipError_t launch_spd_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
-    return launch_tile4_f64<true>(n, A, X, batch, info, stream);
+    return launch_tile4<T, true>(n, A, X, batch, info, stream);
 }
+template hipError_t launch_gj_tile4<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
+template hipError_t launch_gj_tile4<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
+template hipError_t launch_spd_tile4<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
+template hipError_t launch_spd_tile4<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
 
-const char *name_spd_tile4_f64(int n)
+const char *name_tile4(bool f64, bool spd, int n)
 {
-    const bool full = (n % 16) == 0;
-    switch ((n + 15) / 16) {
-    case 5: return full ? "matinv_gj_tile4_f64<5, true, 4, true>" : "matinv_gj_tile4_f64<5, false, 4, true>";
-    case 6: return full ? "matinv_gj_tile4_f64<6, true, 4, true>" : "matinv_gj_tile4_f64<6, false, 4, true>";
-    case 7: return full ? "matinv_gj_tile4_f64<7, true, 4, true>" : "matinv_gj_tile4_f64<7, false, 4, true>";
-    default: return full ? "matinv_gj_tile4_f64<8, true, 4, true>" : "matinv_gj_tile4_f64<8, false, 4, true>";
-    }
-}
-
-const char *name_gj_tile4_f64(int n)
-{
-    const bool full = (n % 16) == 0;
-    switch ((n + 15) / 16) {
-    case 5: return full ? "matinv_gj_tile4_f64<5, true>" : "matinv_gj_tile4_f64<5, false>";
-    case 6: return full ? "matinv_gj_tile4_f64<6, true>" : "matinv_gj_tile4_f64<6, false>";
-    case 7: return full ? "matinv_gj_tile4_f64<7, true>" : "matinv_gj_tile4_f64<7, false>";
-    default: return full ? "matinv_gj_tile4_f64<8, true>" : "matinv_gj_tile4_f64<8, false>";
-    }
+    static thread_local char buf[64];
+    snprintf(buf, sizeof buf, "matinv_gj_tile4_%s<%d, %s%s>", f64 ? "f64" : "f32", (n + 15) / 16, (n % 16) == 0 ? "true" : "false",
+             spd ? ", 4, true" : "");
+    return buf;
 }
 
 }  // namespace matinv

@@ -508,7 +508,7 @@ bool tile_family_supports(int n);
 template <>
 bool tile_family_supports<double>(int n) { return n >= 1 && n <= 128; }
 template <>
-bool tile_family_supports<float>(int n) { return n >= 1 && n <= 64; }
+bool tile_family_supports<float>(int n) { return n >= 1 && n <= 128; }
 
 template <class T>
 hipError_t launch_gj_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
@@ -518,6 +518,7 @@ hipError_t launch_gj_tile<float>(int n, BatchRef<const float> A, BatchRef<float>
                                  hipStream_t stream)
 {
     if (!tile_family_supports<float>(n)) return hipErrorInvalidValue;
+    if (n > 64) return launch_gj_tile4<float>(n, A, X, batch, info, stream);
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -551,7 +552,7 @@ hipError_t launch_gj_tile<double>(int n, BatchRef<const double> A, BatchRef<doub
 {
     if (!tile_family_supports<double>(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    if (n > 64) return launch_gj_tile4_f64(n, A, X, batch, info, stream);
+    if (n > 64) return launch_gj_tile4<double>(n, A, X, batch, info, stream);
     // work list for matrices that fail the acceptance test: [0] = count, [1..batch] = indices (stream-ordered pool)
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -593,7 +594,7 @@ bool spd_tile_supports(int n);
 template <>
 bool spd_tile_supports<double>(int n) { return n >= 1 && n <= 128; }  // 64 < n <= 128: tile4_kernels.hip
 template <>
-bool spd_tile_supports<float>(int n) { return n >= 1 && n <= 64; }
+bool spd_tile_supports<float>(int n) { return n >= 1 && n <= 128; }
 
 template <class T>
 hipError_t launch_spd_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
@@ -602,6 +603,7 @@ hipError_t launch_spd_tile<float>(int n, BatchRef<const float> A, BatchRef<float
                                   hipStream_t stream)
 {
     if (!spd_tile_supports<float>(n)) return hipErrorInvalidValue;
+    if (n > 64) return launch_spd_tile4<float>(n, A, X, batch, info, stream);
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -634,7 +636,7 @@ hipError_t launch_spd_tile<double>(int n, BatchRef<const double> A, BatchRef<dou
                                    hipStream_t stream)
 {
     if (!spd_tile_supports<double>(n)) return hipErrorInvalidValue;
-    if (n > 64) return launch_spd_tile4_f64(n, A, X, batch, info, stream);
+    if (n > 64) return launch_spd_tile4<double>(n, A, X, batch, info, stream);
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -665,6 +667,7 @@ hipError_t launch_spd_tile<double>(int n, BatchRef<const double> A, BatchRef<dou
 const char *name_spd_tile(bool f64, int n)
 {
     const bool full = (n % 16) == 0;
+    if (n > 64) return name_tile4(f64, true, n);
     if (!f64) {
         switch ((n + 15) / 16) {
         case 1: return full ? "matinv_spd_tile_f32<1, true>" : "matinv_spd_tile_f32<1, false>";
@@ -673,7 +676,6 @@ const char *name_spd_tile(bool f64, int n)
         default: return full ? "matinv_spd_tile_f32<4, true>" : "matinv_spd_tile_f32<4, false>";
         }
     }
-    if (n > 64) return name_spd_tile4_f64(n);
     switch ((n + 15) / 16) {
     case 1: return full ? "matinv_spd_tile_f64<1, true>" : "matinv_spd_tile_f64<1, false>";
     case 2: return full ? "matinv_spd_tile_f64<2, true>" : "matinv_spd_tile_f64<2, false>";
@@ -684,6 +686,7 @@ const char *name_spd_tile(bool f64, int n)
 
 const char *name_gj_tile(bool f64, int n)
 {
+    if (n > 64) return name_tile4(f64, false, n);
     if (!f64) {
         const bool fullf = (n % 16) == 0;
         switch ((n + 15) / 16) {
@@ -693,7 +696,6 @@ const char *name_gj_tile(bool f64, int n)
         default: return fullf ? "matinv_gj_tile_f32<4, true, true>" : "matinv_gj_tile_f32<4, false, true>";
         }
     }
-    if (n > 64) return name_gj_tile4_f64(n);
     const bool full = (n % 16) == 0;
     switch ((n + 15) / 16) {
     case 1: return full ? "matinv_gj_tile_f64<1, true, true>" : "matinv_gj_tile_f64<1, false, true>";
