@@ -366,6 +366,19 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             return MATINV_OK;
         }
     }
+    if (tile4_supports(n)) {
+        static const bool use_tile4 = []() {
+            const char *s = getenv("MATINV_GP_TILE4");  // A/B switch for profiling; default on
+            return !(s && *s == '0');
+        }();
+        if (use_tile4) {
+            hipError_t e4 = launch_gp_tile4<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
+                                               variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
+                                               static_cast<T *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
+            if (e4 != hipSuccess) return fail_hip(e4, "kernel launch");
+            return MATINV_OK;
+        }
+    }
     if (!lds_family_supports<T>(n)) {
         if (!global_family_supports<T>(n)) return fail(MATINV_ERR_UNSUPPORTED, "pipeline: n=%d exceeds the limit 1024", n);
         static const bool use_blocked = []() {

@@ -105,6 +105,10 @@ hipError_t launch_gj_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t bat
 template <class T>
 hipError_t launch_spd_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 const char *name_tile4(bool f64, bool spd, int n);
+// fused GP scalars on the same kernel (SPD sweep of B + diag c, bilinear form from the accumulators), 64 < n <= 128
+template <class T>
+hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                           int *info, hipStream_t stream);
 // SPD (symmetric blocked sweep) on the tile layout, f64, n <= 64
 template <class T>
 hipError_t launch_spd_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);

@@ -29,10 +29,20 @@ namespace matinv {
 // tiles are mirrored while loading, as the Cholesky contract demands -- include/matinv.h), the natural pivots are accepted
 // when they are all POSITIVE (leading principal minors of a symmetric matrix: positive definite; no multiplier test, the
 // sweep is stable on SPD input), and rejected matrices go to the LDS Cholesky, which reports the failing column.
-template <class T, int NT, bool FULL, int T4_WAVES, bool SPD>
+// GP = the fused Gaussian-process scalars for 64 < n <= 128 (SPD mode on M = B + diag c): the diagonal is added while
+// loading, and instead of storing M^-1 every wave folds its tile columns into a^T M^-1 d straight from the accumulator
+// registers (wave reduction, four partial sums through LDS): n^2 elements read, ONE scalar written per item.
+template <class T>
+struct GpArgs {
+    const T *a, *c, *d, *e;  // d == nullptr: variance, out = e - a^T M^-1 a
+    T *out;
+};
+
+template <class T, int NT, bool FULL, int T4_WAVES, bool SPD, bool GP = false>
 __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
-                                              int *work_count, int *work_list, T *panel)
+                                              int *work_count, int *work_list, T *panel, GpArgs<T> gp = GpArgs<T>())
 {
+    static_assert(!GP || SPD, "the fused pipeline runs the SPD sweep");
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
     constexpr int N = 16 * NT;
@@ -70,6 +80,10 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                     // A(col, row); its mirror A(row, col) sits at col * n + row
                     const bool mirror = SPD && (col < row);  // A(col,row) with col < row is an UPPER element: read A(row,col)
                     acc[ti][jl][r] = in ? (mirror ? A[(unsigned)(col * n + row)] : A[uoff + lane_off]) : ((row == col) ? (T)1 : (T)0);
+                    // addDiagonal (gauss_bench.cu:38-43): only the tile slot that can hold the diagonal tile of this tile row
+                    if (GP && jl == ti / T4_WAVES) {
+                        if (w == ti % T4_WAVES && row == col && (FULL || row < n)) acc[ti][jl][r] += gp.c[(size_t)mat * n + row];
+                    }
                 }
             }
         unsigned long long bad = 0;
@@ -203,7 +217,43 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
         }
         __syncthreads();  // both panel buffers are free again before the next matrix stages its first panel
 
-        if (bad == 0) {  // identical in all four waves (they evaluate the same D and the same Aop)
+        if (GP) {
+            if (bad == 0) {
+                // s = sum over this lane's elements a[row] X[row][col] d[col] (X symmetric, so the W = A^T labelling is immaterial)
+                const T *va = gp.a + (size_t)mat * n;
+                const T *vd = gp.d ? gp.d + (size_t)mat * n : va;
+                T s = 0;
+#pragma unroll
+                for (int jl = 0; jl < NC; ++jl) {
+                    const int tj = w + T4_WAVES * jl, col = 16 * tj + c;
+                    T t = 0;
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * ti + G::trow(r, q);
+                            const T ar = (FULL || ti < NT - 1 || row < n) ? va[row] : (T)0;  // identity padding contributes nothing
+                            t = fma_t(ar, acc[ti][jl][r], t);
+                        }
+                    const T dc = (tj < NT && (FULL || col < n)) ? vd[col] : (T)0;
+                    s = fma_t(dc, t, s);
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+                if (l == 0) panel[w] = s;  // both panel buffers are free (barrier above)
+            }
+            __syncthreads();
+            if (bad == 0 && threadIdx.x == 0) {
+                T sum = 0;
+#pragma unroll
+                for (int i = 0; i < T4_WAVES; ++i) sum += panel[i];
+                gp.out[mat] = gp.d ? sum : gp.e[mat] - sum;
+            }
+            __syncthreads();  // the next matrix stages its first panel into the same buffer
+        }
+        if (GP && bad == 0) {
+            if (info && threadIdx.x == 0) info[mat] = 0;
+        } else if (bad == 0) {  // identical in all four waves (they evaluate the same D and the same Aop)
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -241,6 +291,30 @@ __global__ __launch_bounds__(64 * T4_WAVES, 3) void matinv_gj_tile4_f32(BatchRef
 {
     __shared__ __attribute__((aligned(16))) float panel[2 * 16 * NT * 4];
     gj_tile4_body<float, NT, FULL, T4_WAVES, SPD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
+}
+
+// fused mean / variance, 64 < n <= 128 (run-time n only: one instantiation per NT and dtype)
+template <int NT>
+__global__ __launch_bounds__(256, 2) void matinv_gp_tile4_f64(const double *As, const double *Bs, const double *Cs, const double *Ds,
+                                                             const double *Es, double *out, int *info, int n_rt, unsigned batch,
+                                                             int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) double panel[2 * 16 * NT * 4];
+    BatchRef<const double> A{Bs, (size_t)n_rt * n_rt, nullptr};
+    BatchRef<double> X{nullptr, 0, nullptr};
+    gj_tile4_body<double, NT, false, 4, true, true>(A, X, info, n_rt, batch, work_count, work_list, panel,
+                                                   GpArgs<double>{As, Cs, Ds, Es, out});
+}
+template <int NT>
+__global__ __launch_bounds__(256, 3) void matinv_gp_tile4_f32(const float *As, const float *Bs, const float *Cs, const float *Ds,
+                                                             const float *Es, float *out, int *info, int n_rt, unsigned batch,
+                                                             int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) float panel[2 * 16 * NT * 4];
+    BatchRef<const float> A{Bs, (size_t)n_rt * n_rt, nullptr};
+    BatchRef<float> X{nullptr, 0, nullptr};
+    gj_tile4_body<float, NT, false, 4, true, true>(A, X, info, n_rt, batch, work_count, work_list, panel,
+                                                  GpArgs<float>{As, Cs, Ds, Es, out});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -300,6 +374,43 @@ template hipError_t launch_gj_tile4<double>(int, BatchRef<const double>, BatchRe
 template hipError_t launch_gj_tile4<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
 template hipError_t launch_spd_tile4<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
 template hipError_t launch_spd_tile4<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
+
+template <class T>
+hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                           int *info, hipStream_t stream)
+{
+    if (!tile4_supports(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int nt = (n + 15) / 16;
+    const unsigned occ = sizeof(T) == 8 ? 2u : 3u;
+    const unsigned grid = (unsigned)(batch < 256u * occ * 4u ? batch : 256u * occ * 4u);
+    const unsigned b = (unsigned)batch;
+#define GP4_LAUNCH(NT_)                                                                                               \
+    if constexpr (sizeof(T) == 8)                                                                                     \
+        hipLaunchKernelGGL((matinv_gp_tile4_f64<NT_>), dim3(grid), dim3(256), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((matinv_gp_tile4_f32<NT_>), dim3(grid), dim3(256), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1);
+    switch (nt) {
+    case 5: GP4_LAUNCH(5) break;
+    case 6: GP4_LAUNCH(6) break;
+    case 7: GP4_LAUNCH(7) break;
+    default: GP4_LAUNCH(8) break;
+    }
+#undef GP4_LAUNCH
+    e = hipGetLastError();
+    if (e == hipSuccess) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
+    hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+template hipError_t launch_gp_tile4<double>(int, const double *, const double *, const double *, const double *, const double *,
+                                            double *, size_t, int *, hipStream_t);
+template hipError_t launch_gp_tile4<float>(int, const float *, const float *, const float *, const float *, const float *, float *,
+                                           size_t, int *, hipStream_t);
 
 const char *name_tile4(bool f64, bool spd, int n)
 {

@@ -408,7 +408,7 @@ def test_pipeline_fixtures(d, n, gold):
     assert np.abs(v - r["variances"]).mean() < 5e-5
 
 
-@pytest.mark.parametrize("n", [1, 5, 16, 33, 64, 128])
+@pytest.mark.parametrize("n", [1, 5, 16, 33, 64, 65, 80, 100, 127, 128, 129])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_pipeline_synthetic(n, dtype):
     rng = np.random.default_rng(n)
@@ -425,11 +425,12 @@ def test_pipeline_synthetic(n, dtype):
     assert np.abs(m - wm).max() < tol and np.abs(v - wv).max() < tol
 
 
-def test_pipeline_not_spd_reports_info_and_nan():
-    n, batch = 32, 6
+@pytest.mark.parametrize("n", [32, 100])
+def test_pipeline_not_spd_reports_info_and_nan(n):
+    batch = 6
     rng = np.random.default_rng(5)
     B = spd_batch(n, batch, seed=5).reshape(batch, n, n)
-    B[3, 7, 7] = -50.0                       # breaks positive definiteness of item 3
+    B[3, 7, 7] = -50.0 * n                   # breaks positive definiteness of item 3
     a, c, d_ = (rng.random(batch * n) for _ in range(3))
     t = [dev(x) for x in (a, B.reshape(-1), c, d_)]
     info = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
