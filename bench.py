@@ -119,14 +119,25 @@ def run_mixed(args, api, device, rank, world):
             q.submit_many(*ch)
         return q.flush()[0]
 
+    import torch.distributed as tdist
+    multi = world > 1 and tdist.is_initialized()
     for _ in range(max(1, args.warmup)):
         step()
+    if multi:
+        tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    if multi:
+        tdist.barrier()
     elapsed = time.perf_counter() - t0
+    if multi:  # max over ranks
+        backend_dev = device if tdist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=backend_dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t[0].item())
     per_bin = {}
     for n, cnt in mix.items():  # kernel-only rate of each bin (batched, device resident)
         sel = [it for it in items if it[0].numel() == n]
