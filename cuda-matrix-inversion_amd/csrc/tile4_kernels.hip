@@ -414,9 +414,10 @@ template hipError_t launch_gp_tile4<float>(int, const float *, const float *, co
 
 const char *name_tile4(bool f64, bool spd, int n)
 {
+    // as rocprofv3 prints the instantiation (default template arguments spelled out)
     static thread_local char buf[64];
-    snprintf(buf, sizeof buf, "matinv_gj_tile4_%s<%d, %s%s>", f64 ? "f64" : "f32", (n + 15) / 16, (n % 16) == 0 ? "true" : "false",
-             spd ? ", 4, true" : "");
+    snprintf(buf, sizeof buf, "matinv_gj_tile4_%s<%d, %s, 4, %s>", f64 ? "f64" : "f32", (n + 15) / 16, (n % 16) == 0 ? "true" : "false",
+             spd ? "true" : "false");
     return buf;
 }
 
