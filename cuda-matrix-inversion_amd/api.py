@@ -19,7 +19,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (ALGO_CHOLESKY, ALGO_GAUSS_JORDAN, F32, F64, KERNEL_AUTO, KERNEL_GLOBAL, KERNEL_LDS,  # noqa: F401
+from ._lib import (ALGO_CHOLESKY, ALGO_GAUSS_JORDAN, F32, F64, KERNEL_AUTO, KERNEL_BLOCKED, KERNEL_GLOBAL, KERNEL_LDS,  # noqa: F401
                    KERNEL_ROW, KERNEL_ROWLANE, KERNEL_TILE, MatinvError)
 
 

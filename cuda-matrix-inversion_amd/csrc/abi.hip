@@ -60,6 +60,8 @@ int select_auto(int algo, int n)
         if (tile_family_supports<T>(n)) return MATINV_KERNEL_TILE;
     } else if (spd_tile_supports<T>(n)) {
         return MATINV_KERNEL_TILE;
+    } else if (blocked_inverse_supports(n)) {
+        return MATINV_KERNEL_BLOCKED;  // SPD inverse beyond the four-wave kernel
     }
     if (lds_family_supports<T>(n)) return MATINV_KERNEL_LDS;
     if (global_family_supports<T>(n)) return MATINV_KERNEL_GLOBAL;
@@ -112,6 +114,11 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
             return fail(MATINV_ERR_UNSUPPORTED, "global family serves full inversions with n <= 1024 only (n=%d)", n);
         e = (algo == MATINV_ALGO_GAUSS_JORDAN) ? launch_gj_global<T>(n, A, X, batch, dInfo, stream)
                                                : launch_chol_global<T>(n, A, X, batch, dInfo, stream);
+        break;
+    case MATINV_KERNEL_BLOCKED:
+        if (algo != MATINV_ALGO_CHOLESKY || !blocked_inverse_supports(n) || chol_phases != 7)
+            return fail(MATINV_ERR_UNSUPPORTED, "blocked family serves the full SPD inverse with n <= 1024 only (n=%d)", n);
+        e = launch_chol_blocked<T>(n, A, X, batch, dInfo, stream);
         break;
     case MATINV_KERNEL_ROW:
         if (algo != MATINV_ALGO_GAUSS_JORDAN || !row_family_supports<T>(n))
@@ -509,6 +516,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     case MATINV_KERNEL_TILE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_tile(f64, n) : name_gj_tile(f64, n);
     case MATINV_KERNEL_ROW: return name_gj_row(f64, n);
     case MATINV_KERNEL_GLOBAL: return algo == MATINV_ALGO_CHOLESKY ? name_chol_global(f64) : name_gj_global(f64);
+    case MATINV_KERNEL_BLOCKED: return f64 ? "matinv_bgp_panel<double>" : "matinv_bgp_panel<float>";
     default: return "";
     }
 }

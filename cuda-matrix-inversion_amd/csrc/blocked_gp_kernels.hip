@@ -46,13 +46,13 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_init(const T *As, cons
 }
 
 template <class T>
-__global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_panel(T *W, int n, int k0, int *status)
+__global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_panel(T *W, int n, int ld, int row_end, int k0, int *status)
 {
     constexpr int LD = BGP_PB + 1;
     __shared__ T L11[BGP_PB * LD];  // column-major, L11[c * LD + r]
     __shared__ T rinv[BGP_PB];
     const size_t item = blockIdx.y;
-    const int ld = n + 2, pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB, t = threadIdx.x;
+    const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB, t = threadIdx.x;
     T *w = W + item * (size_t)ld * n;
     if (status[item] != 0) return;  // an earlier panel found a non-positive pivot
     for (int e = t; e < BGP_PB * BGP_PB; e += BGP_THREADS) {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_panel(T *W, int n, int
     // one row per thread: x L11^T = row, right-looking (once x[c] is final it is eliminated from the later entries, so
     // the dependent chain is PB long and the inner updates are independent FMAs)
     const int r = k0 + pb + blockIdx.x * BGP_THREADS + t;
-    if (r >= ld) return;
+    if (r >= row_end) return;  // rows beyond row_end are still zero in these columns (identity border of the inversion)
     T x[BGP_PB];
 #pragma unroll
     for (int c = 0; c < BGP_PB; ++c) {
@@ -97,14 +97,14 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_panel(T *W, int n, int
 
 // trailing update: W[I, J] -= L[I, K] L[J, K]^T for 64 x 64 tiles with J >= k0 + pb, I >= J (rows up to n + 1)
 template <class T>
-__global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, int k0, const int *status)
+__global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, int ld, int row_end, int k0, const int *status)
 {
     __shared__ T Li[BGP_KS][BGP_TILE + 1], Lj[BGP_KS][BGP_TILE + 1];
     const size_t item = blockIdx.z;
     if (status[item] != 0) return;
-    const int ld = n + 2, pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
+    const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
     const int j0 = k0 + pb + blockIdx.x * BGP_TILE, i0 = k0 + pb + blockIdx.y * BGP_TILE;
-    if (j0 >= n || i0 >= ld || i0 + BGP_TILE <= j0) return;  // outside, or strictly above the diagonal
+    if (j0 >= n || i0 >= row_end || i0 + BGP_TILE <= j0) return;  // outside, or strictly above the diagonal
     T *w = W + item * (size_t)ld * n;
     const int t = threadIdx.x;
     const int ti = (t & 15) * 4, tj = (t >> 4) * 4;  // 4 x 4 outputs per thread: rows i0+ti.., columns j0+tj..
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, in
         __syncthreads();
         for (int e = t; e < kd * BGP_TILE; e += BGP_THREADS) {
             const int k = e / BGP_TILE, r = e - k * BGP_TILE;
-            Li[k][r] = (i0 + r < ld) ? w[(size_t)(k0 + ks + k) * ld + i0 + r] : (T)0;
+            Li[k][r] = (i0 + r < row_end) ? w[(size_t)(k0 + ks + k) * ld + i0 + r] : (T)0;
             Lj[k][r] = (j0 + r < n) ? w[(size_t)(k0 + ks + k) * ld + j0 + r] : (T)0;
         }
         __syncthreads();
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, in
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = i0 + ti + u, c = j0 + tj + v;
-            if (r < ld && c < n && r >= c) w[(size_t)c * ld + r] -= acc[u][v];
+            if (r < row_end && c < n && r >= c) w[(size_t)c * ld + r] -= acc[u][v];
         }
 }
 
@@ -178,11 +178,11 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
     for (int k0 = 0; k0 < n; k0 += BGP_PB) {
         const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
         const unsigned chunks = (unsigned)((ld - (k0 + pb) + BGP_THREADS - 1) / BGP_THREADS);  // >= 1: the border rows
-        hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, (unsigned)batch), dim3(BGP_THREADS), 0, stream, W, n, k0, status);
+        hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, (unsigned)batch), dim3(BGP_THREADS), 0, stream, W, n, ld, ld, k0, status);
         const int rem_cols = n - (k0 + BGP_PB), rem_rows = ld - (k0 + BGP_PB);
         if (rem_cols > 0) {
             const unsigned gx = (rem_cols + BGP_TILE - 1) / BGP_TILE, gy = (rem_rows + BGP_TILE - 1) / BGP_TILE;
-            hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, (unsigned)batch), dim3(BGP_THREADS), 0, stream, W, n, k0, status);
+            hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, (unsigned)batch), dim3(BGP_THREADS), 0, stream, W, n, ld, ld, k0, status);
         }
     }
     hipLaunchKernelGGL(matinv_bgp_finish<T>, dim3((unsigned)batch), dim3(BGP_THREADS), 0, stream, W, Ds ? nullptr : Es, out, info,
@@ -195,5 +195,119 @@ template hipError_t launch_gp_blocked<double>(int, const double *, const double 
                                               const double *, double *, size_t, int *, hipStream_t);
 template hipError_t launch_gp_blocked<float>(int, const float *, const float *, const float *, const float *, const float *,
                                              float *, size_t, int *, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------------------------
+// SPD INVERSE for large n (MATINV_ALGO_CHOLESKY beyond the four-wave kernel, n <= 1024) on the same two kernels: the border
+// is the n x n IDENTITY (ld = 2n). After the factorisation border row i holds (L^-1 e_i)^T, i.e. the border block is
+// Y = L^-T, and A^-1 = L^-T L^-1 = Y Y^T is one symmetric rank-n product (matinv_binv_syrk). Border row i is still zero in
+// the columns of a panel until the panel reaches column i, so the panel and update launches stop at row n + k0 + pb:
+// n^3/3 flops each for the factor, the triangular inverse and the product -- the three phases of
+// /root/reference/src/inverse_cholesky_cpu.c:17-85 in blocked form. Only the lower triangle of A is read.
+template <class T>
+__global__ __launch_bounds__(BGP_THREADS) void matinv_binv_init(BatchRef<const T> Ain, size_t first, T *W, int n, int *status)
+{
+    const size_t item = blockIdx.y;
+    const int ld = 2 * n;
+    T *w = W + item * (size_t)ld * n;
+    const T *A = Ain.at(first + item);
+    for (size_t e = (size_t)blockIdx.x * BGP_THREADS + threadIdx.x; e < (size_t)ld * n; e += (size_t)gridDim.x * BGP_THREADS) {
+        const int c = (int)(e / ld), r = (int)(e - (size_t)c * ld);
+        w[e] = (r < n) ? ((r >= c) ? A[(size_t)c * n + r] : (T)0) : ((r - n == c) ? (T)1 : (T)0);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) status[item] = 0;
+}
+
+// X[i][j] = sum_{c >= max(i,j)} Y[i][c] Y[j][c]; one workgroup per 64 x 64 tile with j0 <= i0, mirrored on write
+template <class T>
+__global__ __launch_bounds__(BGP_THREADS) void matinv_binv_syrk(const T *W, BatchRef<T> Xout, size_t first, int *info, int n,
+                                                                const int *status)
+{
+    __shared__ T Yi[BGP_KS][BGP_TILE + 1], Yj[BGP_KS][BGP_TILE + 1];
+    const size_t item = blockIdx.z;
+    const int j0 = blockIdx.x * BGP_TILE, i0 = blockIdx.y * BGP_TILE;
+    if (j0 > i0) return;
+    const int ld = 2 * n, t = threadIdx.x;
+    const T *w = W + item * (size_t)ld * n;
+    T *X = Xout.at(first + item);
+    const int bad = status[item];
+    const int ti = (t & 15) * 4, tj = (t >> 4) * 4;
+    T acc[4][4] = {};
+    if (!bad) {
+        for (int c0 = i0; c0 < n; c0 += BGP_KS) {  // Y[i][c] = 0 for c < i: start at the tile's first row
+            const int kd = (n - c0 < BGP_KS) ? n - c0 : BGP_KS;
+            __syncthreads();
+            for (int e = t; e < kd * BGP_TILE; e += BGP_THREADS) {
+                const int k = e / BGP_TILE, r = e - k * BGP_TILE;
+                Yi[k][r] = (i0 + r < n) ? w[(size_t)(c0 + k) * ld + n + i0 + r] : (T)0;
+                Yj[k][r] = (j0 + r < n) ? w[(size_t)(c0 + k) * ld + n + j0 + r] : (T)0;
+            }
+            __syncthreads();
+            for (int k = 0; k < kd; ++k) {
+                T a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = Yi[k][ti + u]; b[u] = Yj[k][tj + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + ti + u, j = j0 + tj + v;
+            if (i < n && j < n) {
+                const T x = bad ? nan_of<T>() : acc[u][v];
+                X[(size_t)j * n + i] = x;
+                if (i0 != j0) X[(size_t)i * n + j] = x;  // off-diagonal tiles fill their mirror image
+            }
+        }
+    if (info && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) info[first + item] = bad;
+}
+
+bool blocked_inverse_supports(int n) { return n >= 1 && n <= 1024; }
+
+template <class T>
+hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    if (!blocked_inverse_supports(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    const int ld = 2 * n;
+    // chunks: grid.y / grid.z limit and a bounded workspace (<= 4 GiB)
+    size_t chunk = (size_t)(4ull << 30) / ((size_t)ld * n * sizeof(T));
+    if (chunk < 1) chunk = 1;
+    if (chunk > 65535) chunk = 65535;
+    if (chunk > batch) chunk = batch;
+    T *W = nullptr;
+    int *status = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&W), chunk * (size_t)ld * n * sizeof(T), stream);
+    if (e != hipSuccess) return e;
+    e = hipMallocAsync(reinterpret_cast<void **>(&status), chunk * sizeof(int), stream);
+    if (e != hipSuccess) { (void)hipFreeAsync(W, stream); return e; }
+    for (size_t first = 0; first < batch; first += chunk) {
+        const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
+        hipLaunchKernelGGL(matinv_binv_init<T>, dim3(64, b), dim3(BGP_THREADS), 0, stream, A, first, W, n, status);
+        for (int k0 = 0; k0 < n; k0 += BGP_PB) {
+            const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
+            const int row_end = n + k0 + pb;  // border rows beyond it are still zero in these columns
+            const unsigned chunks = (unsigned)((row_end - (k0 + pb) + BGP_THREADS - 1) / BGP_THREADS);
+            hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, n, ld, row_end, k0, status);
+            const int rem_cols = n - (k0 + BGP_PB), rem_rows = row_end - (k0 + BGP_PB);
+            if (rem_cols > 0) {
+                const unsigned gx = (rem_cols + BGP_TILE - 1) / BGP_TILE, gy = (rem_rows + BGP_TILE - 1) / BGP_TILE;
+                hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, b), dim3(BGP_THREADS), 0, stream, W, n, ld, row_end, k0, status);
+            }
+        }
+        const unsigned g = (unsigned)((n + BGP_TILE - 1) / BGP_TILE);
+        hipLaunchKernelGGL(matinv_binv_syrk<T>, dim3(g, g, b), dim3(BGP_THREADS), 0, stream, W, X, first, info, n, status);
+    }
+    e = hipGetLastError();
+    hipError_t e2 = hipFreeAsync(W, stream), e3 = hipFreeAsync(status, stream);
+    return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
+}
+template hipError_t launch_chol_blocked<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
+template hipError_t launch_chol_blocked<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
 
 }  // namespace matinv

@@ -70,6 +70,11 @@ template <class T>
 hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
                              int *info, hipStream_t stream);
 
+// blocked SPD inverse for large n on the same panel / update kernels (identity border + symmetric rank-n product)
+bool blocked_inverse_supports(int n);
+template <class T>
+hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+
 // GLOBAL family (global_kernels.hip): any n <= 1024, working copy in global memory
 template <class T>
 bool global_family_supports(int n);

@@ -52,13 +52,16 @@ typedef enum {
     MATINV_KERNEL_AUTO = 0,
     MATINV_KERNEL_LDS = 1,     /* one workgroup per matrix, matrix resident in LDS, any n up to the LDS limit */
     MATINV_KERNEL_ROWLANE = 2, /* n <= 16: 64/npad matrices per wavefront, one row per lane, DPP broadcasts     */
-    MATINV_KERNEL_TILE = 3     /* 16x16 MFMA accumulator tiles: blocked Gauss-Jordan with one wavefront per matrix (n <= 64,
-                                  f64 and f32) or four (64 < n <= 128, f64); for MATINV_ALGO_CHOLESKY the symmetric blocked
-                                  sweep on lower-triangular tiles (n <= 64, f64) */,
+    MATINV_KERNEL_TILE = 3     /* 16x16 MFMA accumulator tiles, f64 and f32: blocked Gauss-Jordan with one wavefront per matrix
+                                  (n <= 64) or four (64 < n <= 128); for MATINV_ALGO_CHOLESKY the symmetric blocked sweep on
+                                  lower-triangular tiles (n <= 64) / the four-wave sweep with positivity-checked pivots */,
     MATINV_KERNEL_ROW = 4,     /* n <= 64: one matrix per wavefront, row per lane, classical partial pivoting with the pivot
                                   row broadcast through v_readlane; the pivoting path behind the tile family */
-    MATINV_KERNEL_GLOBAL = 5   /* any n <= 1024 (the reference's limit): one 1024-thread workgroup per matrix, working copy
+    MATINV_KERNEL_GLOBAL = 5,  /* any n <= 1024 (the reference's limit): one 1024-thread workgroup per matrix, working copy
                                   in global memory; the functional path for matrices that do not fit on chip */
+    MATINV_KERNEL_BLOCKED = 6  /* MATINV_ALGO_CHOLESKY, any n <= 1024: blocked right-looking Cholesky on a global-memory working
+                                  copy, two launches per 64-column panel over the whole batch, A^-1 = L^-T L^-1 as one symmetric
+                                  product; the automatic choice for SPD inversions beyond n = 128 */
 } matinv_kernel;
 
 /* Invert `batch` matrices that are already resident in device memory.

@@ -208,6 +208,30 @@ def test_large_n_global_family(n, batch):
         api.inverse_batched(torch.zeros(4, dtype=torch.float64, device="cuda"), 1025, GJ, batch=0 + 1)
 
 
+@pytest.mark.parametrize("n,batch,dtype", [(129, 9, "f64"), (200, 5, "f64"), (333, 3, "f64"), (512, 2, "f32"), (1000, 2, "f32")])
+def test_cholesky_large_n_blocked(n, batch, dtype):
+    """SPD inverse beyond the four-wave kernel: blocked Cholesky with an identity border + symmetric product
+    (blocked_gp_kernels.hip). Ragged panels / tiles, garbage in the strict upper triangle (must not be read), an item that
+    is not positive definite (info = failing column, NaN result, neighbours untouched), both precisions."""
+    a = spd_batch(n, batch, seed=40 + n)
+    want, _ = oracle.inverse_batched(a, n, oracle.ALGO_CHOLESKY)
+    dirty = a.reshape(batch, n, n).copy()
+    iu = np.triu_indices(n, 1)
+    dirty[:, iu[1], iu[0]] = 1e30                      # strict upper triangle (memory is [k, col, row])
+    bad = batch - 1
+    dirty[bad, n // 3, n // 3] = -1.0                   # pivot n/3 turns negative
+    np_t = np.float64 if dtype == "f64" else np.float32
+    assert api.select_kernel(CH, api.F64 if dtype == "f64" else api.F32, n) == api.KERNEL_BLOCKED
+    got, info = gpu_inverse(dirty.reshape(-1).astype(np_t), n, CH, want_info=True)
+    got = got.astype(np.float64)
+    assert info.tolist() == [0] * (batch - 1) + [n // 3 + 1]
+    assert np.isnan(as_mats(got, n)[bad]).all()
+    g, w_ = as_mats(got, n)[:bad], as_mats(want, n)[:bad]
+    err = (np.linalg.norm((g - w_).reshape(bad, -1), axis=1) / np.linalg.norm(w_.reshape(bad, -1), axis=1)).max()
+    assert err < (1e-12 if dtype == "f64" else 2e-5)
+    assert np.array_equal(g, g.transpose(0, 2, 1))     # mirrored on write: exactly symmetric
+
+
 def test_large_n_singular_and_fp32():
     n = 160
     a = spd_batch(n, 3, seed=1).reshape(3, n, n)
