@@ -1,5 +1,5 @@
 // global_kernels.hip -- kernel family "GLOBAL": any n up to 1024 (the reference's own limit: one thread per row,
-// /root/reference/src/gauss/batched_invert.cu:87-93), for sizes whose matrix no longer fits on chip (n > 141 in f64,
+// /root/reference/src/gauss/batched_invert.cu:87-93), for sizes whose matrix no longer fits on chip (n > 137 in f64,
 // n > 200 in f32). One 1024-thread workgroup per matrix; the n x n working copy lives in the OUTPUT buffer (global memory,
 // L2 / Infinity-Cache resident for the sizes in question) and only the pivot row and multiplier column of the current
 // step are staged in LDS. Same arithmetic as the LDS family:

@@ -1,6 +1,6 @@
 // lds_kernels.hip -- kernel family "LDS": one 256-thread workgroup per matrix, the whole n x n matrix
 // resident in the CU's 160 KiB LDS, read from HBM once and written once. It serves every n up to the LDS
-// limit (n <= 141 for f64, n <= 200 for f32) and both algorithms, and is the fallback under the faster
+// limit (n <= 137 for f64, n <= 197 for f32) and both algorithms, and is the fallback under the faster
 // register-resident families.
 //
 //   matinv_gj_lds    in-place Gauss-Jordan with partial (row) pivoting. One launch replaces the 3n launches
@@ -22,8 +22,8 @@ __host__ __device__ inline int lds_ld(int n) { return n | 1; }  // odd leading d
 template <class T>
 __host__ __device__ inline size_t lds_bytes(int n)
 {
-    // matrix + multiplier column + pivot row + staging vector + int pivots + reduction scratch
-    return sizeof(T) * ((size_t)n * lds_ld(n) + 3 * (size_t)n) + sizeof(int) * (size_t)n + 64;
+    // matrix + 8 staged pivot rows (blocked Gauss-Jordan) + exchange / broadcast rows + int pivots
+    return sizeof(T) * ((size_t)n * lds_ld(n) + 8 * (size_t)n + 32) + sizeof(int) * (size_t)n + 64;
 }
 
 template <class T>
@@ -44,17 +44,71 @@ template <class T>
 __device__ __forceinline__ T absval(T v) { return v < 0 ? -v : v; }
 
 // ------------------------------------------------------------------------------------------------
-// One matrix, whole workgroup. Block-uniform control flow; ends with every LDS access retired
-// (callers that loop must __syncthreads() before the next matrix).
+// One matrix, whole workgroup: in-place Gauss-Jordan with PARTIAL PIVOTING, blocked over panels of GJ_PB columns.
+//   phase 1  the n x GJ_PB panel lives in registers, thread t <-> row t: per column a workgroup-wide argmax (lowest index on
+//            ties, the oracle's rule), the two rows change places between their threads, the pivot row is broadcast through
+//            LDS and every thread eliminates its own row -- in the panel columns only. Afterwards the panel columns hold
+//            G[:, K], the K columns of the accumulated transform G = G_8 P_8 ... G_1 P_1 (the in-place "inverse part").
+//   phase 2  every other column takes the same row swaps, its old pivot entries b = x[K] are set aside, and
+//            x <- x (K entries zeroed) + G[:, K] b  is a rank-GJ_PB update from register tiles (16 x 16 thread grid, rows
+//            ti + 16u, columns tj + 16v): each matrix element is touched once per PANEL, not once per column.
+// Same pivots as the column-by-column algorithm (the panel columns carry all earlier updates when they are searched).
+// Block-uniform control flow; ends with every LDS access retired (callers that loop must __syncthreads() before the next
+// matrix).
+constexpr int GJ_PB = 8;
+
+namespace {
+constexpr int LDPP_QUAD_XOR1 = 0xB1, LDPP_QUAD_XOR2 = 0x4E, LDPP_ROW_MIRROR = 0x140, LDPP_ROW_HALF_MIRROR = 0x141;
+template <int CTRL>
+__device__ __forceinline__ unsigned ldppu(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+// maximum over the 64 lanes, wave-uniform: 4 DPP steps inside the rows of 16, then 4 v_readlane (no LDS traffic, unlike
+// the ds_bpermute behind __shfl_down)
+__device__ __forceinline__ unsigned lds_wave_max_u32(unsigned v)
+{
+    v = max(v, ldppu<LDPP_QUAD_XOR1>(v));
+    v = max(v, ldppu<LDPP_QUAD_XOR2>(v));
+    v = max(v, ldppu<LDPP_ROW_HALF_MIRROR>(v));
+    v = max(v, ldppu<LDPP_ROW_MIRROR>(v));
+    const unsigned m0 = __builtin_amdgcn_readlane(v, 0), m1 = __builtin_amdgcn_readlane(v, 16);
+    const unsigned m2 = __builtin_amdgcn_readlane(v, 32), m3 = __builtin_amdgcn_readlane(v, 48);
+    const unsigned a = m0 > m1 ? m0 : m1, b = m2 > m3 ? m2 : m3;
+    return a > b ? a : b;
+}
+// largest |v| among the lanes with `active` and the LOWEST lane attaining it (the bit pattern of a non-negative IEEE number
+// orders like the number): exact, two 32-bit rounds for double. Returns the lane (0 when nothing is active), *best = the value.
+__device__ __forceinline__ int wave_argmax_abs(double v, bool active, double *best)
+{
+    const unsigned long long bits = active ? ((unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull) : 0ull;
+    const unsigned hi = (unsigned)(bits >> 32), lo = (unsigned)bits;
+    const unsigned mhi = lds_wave_max_u32(hi);
+    const unsigned mlo = lds_wave_max_u32(hi == mhi ? lo : 0u);
+    const unsigned long long vote = __ballot(active && hi == mhi && lo == mlo);
+    *best = __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
+    return vote ? (int)__builtin_ctzll(vote) : 0;
+}
+__device__ __forceinline__ int wave_argmax_abs(float v, bool active, float *best)
+{
+    const unsigned key = active ? (__float_as_uint(v) & 0x7fffffffu) : 0u;
+    const unsigned mx = lds_wave_max_u32(key);
+    const unsigned long long vote = __ballot(active && key == mx);
+    *best = __uint_as_float(mx);
+    return vote ? (int)__builtin_ctzll(vote) : 0;
+}
+}  // namespace
+
 template <class T>
 __device__ __forceinline__ void gj_lds_one(const T *A, T *X, int *info_slot, int n, unsigned char *smem_raw,
                                            T *s_red_val, int *s_red_idx)
 {
     const int ld = lds_ld(n);
     T *a = reinterpret_cast<T *>(smem_raw);  // a[c*ld + r]
-    T *mcol = a + (size_t)n * ld;            // multipliers of the current step
-    T *prow = mcol + n;                      // pivot row of the current step
-    int *piv = reinterpret_cast<int *>(prow + 2 * n);  // (prow + n .. prow + 2n is spare)
+    T *bbuf = a + (size_t)n * ld;            // [GJ_PB][n]: old pivot-row entries of the non-panel columns
+    T *xch = bbuf + GJ_PB * n;               // [2][GJ_PB] row exchange, then [GJ_PB] pivot row broadcast
+    T *prow = xch + 2 * GJ_PB;
+    int *piv = reinterpret_cast<int *>(prow + GJ_PB);
 
     const int t = threadIdx.x;
     const int tx = t & 63, ty = t >> 6;
@@ -63,63 +117,107 @@ __device__ __forceinline__ void gj_lds_one(const T *A, T *X, int *info_slot, int
         for (int r = tx; r < n; r += 64) a[c * ld + r] = A[(size_t)c * n + r];
     __syncthreads();
 
-    for (int k = 0; k < n; ++k) {
-        // 1. pivot = largest |a[i][k]|, i >= k; lowest index wins ties (same rule as the oracle's scan)
-        T best = (T)-1;
-        int bi = k;
-        for (int i = k + t; i < n; i += LDS_THREADS) {
-            T v = absval(a[k * ld + i]);
-            if (v > best) { best = v; bi = i; }
-        }
-        for (int off = 32; off >= 1; off >>= 1) {
-            T ob = __shfl_down(best, off);
-            int oi = __shfl_down(bi, off);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (tx == 0) { s_red_val[ty] = best; s_red_idx[ty] = bi; }
-        __syncthreads();
-        best = s_red_val[0];
-        int p = s_red_idx[0];
+    for (int k0 = 0; k0 < n; k0 += GJ_PB) {
+        const int pb = (n - k0 < GJ_PB) ? n - k0 : GJ_PB;
+        // ---- phase 1: the panel, one row per thread
+        T x[GJ_PB];
 #pragma unroll
-        for (int w = 1; w < LDS_THREADS / 64; ++w) {
-            T ob = s_red_val[w];
-            int oi = s_red_idx[w];
-            if (ob > best || (ob == best && oi < p)) { best = ob; p = oi; }
+        for (int c = 0; c < GJ_PB; ++c) x[c] = (t < n && c < pb) ? a[(k0 + c) * ld + t] : (T)0;
+#pragma unroll
+        for (int j = 0; j < GJ_PB; ++j) {
+            if (j < pb) {  // block-uniform
+                const int k = k0 + j;
+                T best;
+                int bi = (t & ~63) + wave_argmax_abs(x[j], t >= k && t < n, &best);
+                if (tx == 0) { s_red_val[ty] = best; s_red_idx[ty] = bi; }
+                __syncthreads();
+                best = s_red_val[0];
+                int p = s_red_idx[0];
+#pragma unroll
+                for (int w = 1; w < LDS_THREADS / 64; ++w) {
+                    T ob = s_red_val[w];
+                    int oi = s_red_idx[w];
+                    if (ob > best) { best = ob; p = oi; }  // equal maxima: the lower wave (lower rows) keeps it
+                }
+                if (!(best > 0)) {  // zero or NaN column: singular (block-uniform)
+                    if (info_slot && t == 0) *info_slot = k + 1;
+                    fill_nan(X, n);
+                    return;
+                }
+                if (t == 0) piv[k] = p;
+                // rows k and p change places through LDS, and row p (the pivot row) is what everybody needs: one barrier
+                if (t == k || t == p) {
+                    T *dst = xch + (t == p ? 0 : GJ_PB);  // [0] = the pivot row (row p; also when p == k), [1] = old row k
+#pragma unroll
+                    for (int c = 0; c < GJ_PB; ++c) dst[c] = x[c];
+                }
+                __syncthreads();
+                const T pv = (T)1 / xch[j];
+                if (t == p && p != k) {  // takes over what was in row k
+#pragma unroll
+                    for (int c = 0; c < GJ_PB; ++c) x[c] = xch[GJ_PB + c];
+                }
+                if (t == k) {  // the pivot row: scaled, its pivot entry 1/pivot
+#pragma unroll
+                    for (int c = 0; c < GJ_PB; ++c) x[c] = (c == j) ? pv : xch[c] * pv;
+                } else if (t < n) {
+                    const T m = x[j];
+#pragma unroll
+                    for (int c = 0; c < GJ_PB; ++c) x[c] = (c == j) ? -m * pv : fma(-m, xch[c] * pv, x[c]);
+                }
+            }
         }
-        if (!(best > 0)) {  // zero or NaN column: singular (block-uniform)
-            if (info_slot && t == 0) *info_slot = k + 1;
-            fill_nan(X, n);
-            return;
-        }
-        // 2. swap rows k <-> p while lifting the pivot row out
         if (t < n) {
-            T vp = a[t * ld + p];
-            T vk = a[t * ld + k];
-            a[t * ld + p] = vk;
-            prow[t] = vp;
+#pragma unroll
+            for (int c = 0; c < GJ_PB; ++c)
+                if (c < pb) a[(k0 + c) * ld + t] = x[c];
         }
-        if (t == 0) piv[k] = p;
         __syncthreads();
-        const T inv = (T)1 / prow[k];
-        if (t < n) mcol[t] = (t == k) ? (T)0 : a[k * ld + t];
+        // ---- phase 2: the other columns. Row swaps and the old pivot entries first (thread t <-> column t) ...
+        if (t < n && (t < k0 || t >= k0 + pb)) {
+            T *col = a + t * ld;
+            for (int j = 0; j < pb; ++j) {
+                const int k = k0 + j, p = piv[k];
+                if (p != k) { const T u = col[k]; col[k] = col[p]; col[p] = u; }
+            }
+            for (int j = 0; j < pb; ++j) bbuf[j * n + t] = col[k0 + j];
+        }
         __syncthreads();
-        // 3. eliminate: row k <- scaled pivot row (its k-th entry 1/pivot); row r <- row r - m_r * row k
-        for (int c = ty; c < n; c += LDS_THREADS / 64) {
-            const T pr = (c == k) ? inv : prow[c] * inv;
-            for (int r = tx; r < n; r += 64) {
-                T v;
-                if (r == k) v = pr;
-                else if (c == k) v = -mcol[r] * inv;
-                else v = a[c * ld + r] - mcol[r] * pr;
-                a[c * ld + r] = v;
+        // ... then x <- x (K entries zeroed) + G[:, K] b from register tiles
+        {
+            const int ti = t & 15, tj = t >> 4;
+            for (int ub = 0; 16 * ub < n; ub += 8) {
+                T li[8][GJ_PB];
+#pragma unroll
+                for (int uu = 0; uu < 8; ++uu) {
+                    const int row = ti + 16 * (ub + uu);
+#pragma unroll
+                    for (int c = 0; c < GJ_PB; ++c) li[uu][c] = (row < n && c < pb) ? a[(k0 + c) * ld + row] : (T)0;
+                }
+                for (int col = tj; col < n; col += 16) {
+                    if (col >= k0 && col < k0 + pb) continue;
+                    T bj[GJ_PB];
+#pragma unroll
+                    for (int c = 0; c < GJ_PB; ++c) bj[c] = (c < pb) ? bbuf[c * n + col] : (T)0;
+#pragma unroll
+                    for (int uu = 0; uu < 8; ++uu) {
+                        const int row = ti + 16 * (ub + uu);
+                        if (row < n) {
+                            T v = (row >= k0 && row < k0 + pb) ? (T)0 : a[col * ld + row];
+#pragma unroll
+                            for (int c = 0; c < GJ_PB; ++c) v = fma(li[uu][c], bj[c], v);
+                            a[col * ld + row] = v;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
     }
-    // 4. undo the row swaps as column swaps in reverse order: X[:, j] = a[:, src[j]]
+    // undo the row swaps as column swaps in reverse order: X[:, j] = a[:, src[j]]
     int *src = piv;  // the pivot list becomes the composite column source map
     if (t == 0) {
-        int *s = reinterpret_cast<int *>(mcol);  // mcol/prow are free now
+        int *s = reinterpret_cast<int *>(bbuf);  // free now
         for (int j = 0; j < n; ++j) s[j] = j;
         for (int k = n - 1; k >= 0; --k) {
             int p = piv[k];

@@ -12,7 +12,7 @@
 // next owner stages them into the OTHER half of a double-buffered LDS panel, one workgroup barrier, then the remaining
 // MFMAs run pinned between the stages of the next panel's solve. One barrier per block step.
 // Rejected matrices (a multiplier above TAU) go to the same device work list and are redone by the pivoted LDS kernel,
-// which handles n <= 141.
+// which handles every n this family serves.
 //
 // Replaces, for 64 < n <= 128, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95.
 #include <cstdio>
