@@ -58,6 +58,7 @@ int select_auto(int algo, int n)
     if (algo == MATINV_ALGO_GAUSS_JORDAN) {
         if (rowlane_family_supports<T>(n)) return MATINV_KERNEL_ROWLANE;
         if (tile_family_supports<T>(n)) return MATINV_KERNEL_TILE;
+        if (blocked_gj_supports(n)) return MATINV_KERNEL_BLOCKED;  // beyond n = 128 it beats the LDS kernel at every size measured
     } else if (spd_tile_supports<T>(n)) {
         return MATINV_KERNEL_TILE;
     } else if (blocked_inverse_supports(n)) {
@@ -116,7 +117,12 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
                                                : launch_chol_global<T>(n, A, X, batch, dInfo, stream);
         break;
     case MATINV_KERNEL_BLOCKED:
-        if (algo != MATINV_ALGO_CHOLESKY || !blocked_inverse_supports(n) || chol_phases != 7)
+        if (algo == MATINV_ALGO_GAUSS_JORDAN) {
+            if (!blocked_gj_supports(n)) return fail(MATINV_ERR_UNSUPPORTED, "blocked family: n=%d exceeds the limit 1024", n);
+            e = launch_gj_blocked<T>(n, A, X, batch, dInfo, stream);
+            break;
+        }
+        if (!blocked_inverse_supports(n) || chol_phases != 7)
             return fail(MATINV_ERR_UNSUPPORTED, "blocked family serves the full SPD inverse with n <= 1024 only (n=%d)", n);
         e = launch_chol_blocked<T>(n, A, X, batch, dInfo, stream);
         break;
@@ -516,7 +522,9 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     case MATINV_KERNEL_TILE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_tile(f64, n) : name_gj_tile(f64, n);
     case MATINV_KERNEL_ROW: return name_gj_row(f64, n);
     case MATINV_KERNEL_GLOBAL: return algo == MATINV_ALGO_CHOLESKY ? name_chol_global(f64) : name_gj_global(f64);
-    case MATINV_KERNEL_BLOCKED: return f64 ? "matinv_bgp_panel<double>" : "matinv_bgp_panel<float>";
+    case MATINV_KERNEL_BLOCKED:
+        if (algo == MATINV_ALGO_GAUSS_JORDAN) return f64 ? "matinv_bgj_update<double>" : "matinv_bgj_update<float>";
+        return f64 ? "matinv_bgp_panel<double>" : "matinv_bgp_panel<float>";
     default: return "";
     }
 }

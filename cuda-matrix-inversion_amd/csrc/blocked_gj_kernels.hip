@@ -1,0 +1,281 @@
+// blocked_gj_kernels.hip -- Gauss-Jordan inversion with PARTIAL PIVOTING for LARGE general matrices (beyond what fits in
+// LDS, n <= 1024 = the reference's own limit of one thread per row, /root/reference/src/gauss/batched_invert.cu:87-93).
+//
+// The blocked algorithm of the LDS family (lds_kernels.hip: panel eliminated in registers with thread = row, then a
+// rank-PB update of every other column) spread over the chip: per panel of PB = 32 columns TWO launches over the whole batch,
+//   matinv_bgj_panel   one workgroup per matrix, thread t <-> row t: per column a workgroup-wide arg-max (DPP inside the
+//                      waves, LDS across them; lowest index on ties), the two rows change places through LDS together with
+//                      the pivot-row broadcast, every thread eliminates its row in the panel columns. It then publishes
+//                      the panel columns G[:, K] of the accumulated transform, the row map of this panel's swaps, and the
+//                      old pivot-row entries b = x[K] of every other column;
+//   matinv_bgj_update  one workgroup per 64 x 64 tile: x <- x (rows swapped, K entries zeroed) + G[:, K] b, the two
+//                      operands staged through LDS, 4 x 4 outputs per thread,
+// ping-ponging between two working copies (the swaps are applied as a row gather while reading, so no in-place hazard),
+// and one last launch that undoes the row swaps as column swaps while copying into the caller's buffer. 2 n / 32 + 2
+// launches replace the reference's 3 n (pivotRow / normalizeRow / transform_matrix, batched_invert.cu:84-95); a batch
+// of few large matrices still fills the chip in the update, which is where the 2 n^3 flops are.
+#include "common.hpp"
+
+namespace matinv {
+
+constexpr int BGJ_PB = 32;
+constexpr int BGJ_TILE = 64;
+
+namespace {
+constexpr int GDPP_QUAD_XOR1 = 0xB1, GDPP_QUAD_XOR2 = 0x4E, GDPP_ROW_MIRROR = 0x140, GDPP_ROW_HALF_MIRROR = 0x141;
+template <int CTRL>
+__device__ __forceinline__ unsigned gdppu(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned bgj_wave_max_u32(unsigned v)
+{
+    v = max(v, gdppu<GDPP_QUAD_XOR1>(v));
+    v = max(v, gdppu<GDPP_QUAD_XOR2>(v));
+    v = max(v, gdppu<GDPP_ROW_HALF_MIRROR>(v));
+    v = max(v, gdppu<GDPP_ROW_MIRROR>(v));
+    const unsigned m0 = __builtin_amdgcn_readlane(v, 0), m1 = __builtin_amdgcn_readlane(v, 16);
+    const unsigned m2 = __builtin_amdgcn_readlane(v, 32), m3 = __builtin_amdgcn_readlane(v, 48);
+    const unsigned a = m0 > m1 ? m0 : m1, b = m2 > m3 ? m2 : m3;
+    return a > b ? a : b;
+}
+// largest |v| among the active lanes and the lowest lane attaining it (exact: the bit pattern of a non-negative IEEE number
+// orders like the number)
+__device__ __forceinline__ int bgj_wave_argmax_abs(double v, bool active, double *best)
+{
+    const unsigned long long bits = active ? ((unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull) : 0ull;
+    const unsigned hi = (unsigned)(bits >> 32), lo = (unsigned)bits;
+    const unsigned mhi = bgj_wave_max_u32(hi);
+    const unsigned mlo = bgj_wave_max_u32(hi == mhi ? lo : 0u);
+    const unsigned long long vote = __ballot(active && hi == mhi && lo == mlo);
+    *best = __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
+    return vote ? (int)__builtin_ctzll(vote) : 0;
+}
+__device__ __forceinline__ int bgj_wave_argmax_abs(float v, bool active, float *best)
+{
+    const unsigned key = active ? (__float_as_uint(v) & 0x7fffffffu) : 0u;
+    const unsigned mx = bgj_wave_max_u32(key);
+    const unsigned long long vote = __ballot(active && key == mx);
+    *best = __uint_as_float(mx);
+    return vote ? (int)__builtin_ctzll(vote) : 0;
+}
+}  // namespace
+
+template <class T>
+__global__ __launch_bounds__(256) void matinv_bgj_init(BatchRef<const T> Ain, size_t first, T *W, int n, int *status)
+{
+    const size_t item = blockIdx.y;
+    T *w = W + item * (size_t)n * n;
+    const T *A = Ain.at(first + item);
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)n * n; e += (size_t)gridDim.x * 256) w[e] = A[e];
+    if (blockIdx.x == 0 && threadIdx.x == 0) status[item] = 0;
+}
+
+// blockDim = n rounded up to a multiple of 64 (<= 1024)
+template <class T>
+__global__ __launch_bounds__(1024) void matinv_bgj_panel(const T *Win, T *Wout, T *Bbuf, int *rowsrc, int *pivots, int n, int k0,
+                                                         int *status)
+{
+    __shared__ T s_val[16];
+    __shared__ int s_idx[16];
+    __shared__ T xch[2 * BGJ_PB];
+    __shared__ int rs[1024];
+    const size_t item = blockIdx.x;
+    if (status[item] != 0) return;
+    const T *win = Win + item * (size_t)n * n;
+    T *wout = Wout + item * (size_t)n * n;
+    const int t = threadIdx.x, tx = t & 63, ty = t >> 6, nwaves = blockDim.x >> 6;
+    const int pb = (n - k0 < BGJ_PB) ? n - k0 : BGJ_PB;
+
+    T x[BGJ_PB];
+#pragma unroll
+    for (int c = 0; c < BGJ_PB; ++c) x[c] = (t < n && c < pb) ? win[(size_t)(k0 + c) * n + t] : (T)0;
+    rs[t] = t;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < BGJ_PB; ++j) {
+        if (j < pb) {  // block-uniform
+            const int k = k0 + j;
+            T best;
+            const int bi = (t & ~63) + bgj_wave_argmax_abs(x[j], t >= k && t < n, &best);
+            if (tx == 0) { s_val[ty] = best; s_idx[ty] = bi; }
+            __syncthreads();
+            best = s_val[0];
+            int p = s_idx[0];
+            for (int w = 1; w < nwaves; ++w) {
+                const T ob = s_val[w];
+                const int oi = s_idx[w];
+                if (ob > best) { best = ob; p = oi; }  // equal maxima: the lower wave (lower rows) keeps it
+            }
+            if (!(best > 0)) {  // zero or NaN column: singular (block-uniform)
+                if (t == 0) status[item] = k + 1;
+                return;
+            }
+            if (t == 0) {
+                pivots[item * (size_t)n + k] = p;
+                const int u = rs[k];
+                rs[k] = rs[p];
+                rs[p] = u;
+            }
+            if (t == k || t == p) {
+                T *dst = xch + (t == p ? 0 : BGJ_PB);  // [0] = the pivot row (row p; also when p == k), [1] = old row k
+#pragma unroll
+                for (int c = 0; c < BGJ_PB; ++c) dst[c] = x[c];
+            }
+            __syncthreads();
+            const T pv = (T)1 / xch[j];
+            if (t == p && p != k) {
+#pragma unroll
+                for (int c = 0; c < BGJ_PB; ++c) x[c] = xch[BGJ_PB + c];
+            }
+            if (t == k) {
+#pragma unroll
+                for (int c = 0; c < BGJ_PB; ++c) x[c] = (c == j) ? pv : xch[c] * pv;
+            } else if (t < n) {
+                const T m = x[j];
+#pragma unroll
+                for (int c = 0; c < BGJ_PB; ++c) x[c] = (c == j) ? -m * pv : fma(-m, xch[c] * pv, x[c]);
+            }
+        }
+    }
+    __syncthreads();  // rs is final
+    if (t < n) {
+#pragma unroll
+        for (int c = 0; c < BGJ_PB; ++c)
+            if (c < pb) wout[(size_t)(k0 + c) * n + t] = x[c];
+        rowsrc[item * (size_t)n + t] = rs[t];
+        // old pivot-row entries (after this panel's swaps) of the other columns: thread t <-> column t
+        if (t < k0 || t >= k0 + pb) {
+            const T *col = win + (size_t)t * n;
+            T *b = Bbuf + item * (size_t)BGJ_PB * n;
+            for (int j = 0; j < pb; ++j) b[(size_t)j * n + t] = col[rs[k0 + j]];
+        }
+    }
+}
+
+// x_new[row][col] = (row in K ? 0 : x_old[rowsrc[row]][col]) + sum_k G[row][k] b[k][col]   for the columns outside K
+template <class T>
+__global__ __launch_bounds__(256) void matinv_bgj_update(const T *Win, T *Wout, const T *Bbuf, const int *rowsrc, int n, int k0,
+                                                         const int *status)
+{
+    __shared__ T Gt[BGJ_PB][BGJ_TILE + 1], Bt[BGJ_PB][BGJ_TILE + 1];
+    __shared__ int rsrc[BGJ_TILE];
+    const size_t item = blockIdx.z;
+    if (status[item] != 0) return;
+    const int pb = (n - k0 < BGJ_PB) ? n - k0 : BGJ_PB;
+    const int j0 = blockIdx.x * BGJ_TILE, i0 = blockIdx.y * BGJ_TILE;
+    const T *win = Win + item * (size_t)n * n;
+    T *wout = Wout + item * (size_t)n * n;
+    const T *b = Bbuf + item * (size_t)BGJ_PB * n;
+    const int t = threadIdx.x;
+    for (int e = t; e < BGJ_PB * BGJ_TILE; e += 256) {
+        const int k = e / BGJ_TILE, r = e - k * BGJ_TILE;
+        Gt[k][r] = (k < pb && i0 + r < n) ? wout[(size_t)(k0 + k) * n + i0 + r] : (T)0;
+        Bt[k][r] = (k < pb && j0 + r < n) ? b[(size_t)k * n + j0 + r] : (T)0;
+    }
+    if (t < BGJ_TILE) rsrc[t] = (i0 + t < n) ? rowsrc[item * (size_t)n + i0 + t] : 0;
+    __syncthreads();
+    const int ti = (t & 15) * 4, tj = (t >> 4) * 4;
+    T acc[4][4] = {};
+#pragma unroll 4  // (fully unrolled, hipcc hoists all 256 LDS reads and spills)
+    for (int k = 0; k < BGJ_PB; ++k) {
+        T a[4], bb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = Gt[k][ti + u]; bb[u] = Bt[k][tj + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], bb[v], acc[u][v]);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int col = j0 + tj + v;
+        if (col >= n || (col >= k0 && col < k0 + pb)) continue;  // the panel columns were written by matinv_bgj_panel
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = i0 + ti + u;
+            if (row < n) {
+                const T old = (row >= k0 && row < k0 + pb) ? (T)0 : win[(size_t)col * n + rsrc[ti + u]];
+                wout[(size_t)col * n + row] = old + acc[u][v];
+            }
+        }
+    }
+}
+
+// X[:, j] = W[:, src(j)], src(j) = the pivot swaps applied to the index j in forward order (the row swaps of P A become
+// column swaps of (P A)^-1 in reverse order; following one index through them forwards is the same map)
+template <class T>
+__global__ __launch_bounds__(256) void matinv_bgj_finish(const T *W, BatchRef<T> Xout, size_t first, const int *pivots, int *info,
+                                                         int n, const int *status)
+{
+    __shared__ int piv[1024];
+    __shared__ int src[BGJ_TILE];
+    const size_t item = blockIdx.y;
+    const int j0 = blockIdx.x * BGJ_TILE, t = threadIdx.x;
+    const T *w = W + item * (size_t)n * n;
+    T *X = Xout.at(first + item);
+    const int bad = status[item];
+    if (!bad) {
+        for (int i = t; i < n; i += 256) piv[i] = pivots[item * (size_t)n + i];
+        __syncthreads();
+        if (t < BGJ_TILE && j0 + t < n) {
+            int idx = j0 + t;
+            for (int k = 0; k < n; ++k) {
+                const int p = piv[k];
+                idx = (idx == k) ? p : ((idx == p) ? k : idx);
+            }
+            src[t] = idx;
+        }
+        __syncthreads();
+    }
+    for (int c = t >> 6; c < BGJ_TILE && j0 + c < n; c += 4) {
+        const T *colsrc = bad ? nullptr : w + (size_t)src[c] * n;
+        T *dst = X + (size_t)(j0 + c) * n;
+        for (int r = t & 63; r < n; r += 64) dst[r] = bad ? nan_of<T>() : colsrc[r];
+    }
+    if (info && blockIdx.x == 0 && t == 0) info[first + item] = bad;
+}
+
+bool blocked_gj_supports(int n) { return n >= 1 && n <= 1024; }
+
+template <class T>
+hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    if (!blocked_gj_supports(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    const size_t per_item = (2 * (size_t)n * n + (size_t)BGJ_PB * n) * sizeof(T);
+    size_t chunk = (size_t)(4ull << 30) / per_item;  // bounded workspace, grid.y / grid.z limit
+    if (chunk < 1) chunk = 1;
+    if (chunk > 65535) chunk = 65535;
+    if (chunk > batch) chunk = batch;
+    T *ws = nullptr;
+    int *iws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), chunk * per_item, stream);
+    if (e != hipSuccess) return e;
+    e = hipMallocAsync(reinterpret_cast<void **>(&iws), chunk * (2 * (size_t)n + 1) * sizeof(int), stream);
+    if (e != hipSuccess) { (void)hipFreeAsync(ws, stream); return e; }
+    T *W0 = ws, *W1 = ws + chunk * (size_t)n * n, *Bbuf = W1 + chunk * (size_t)n * n;
+    int *rowsrc = iws, *pivots = iws + chunk * (size_t)n, *status = pivots + chunk * (size_t)n;
+    const unsigned threads = (unsigned)((n + 63) / 64 * 64);
+    const unsigned g = (unsigned)((n + BGJ_TILE - 1) / BGJ_TILE);
+    for (size_t first = 0; first < batch; first += chunk) {
+        const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
+        hipLaunchKernelGGL(matinv_bgj_init<T>, dim3(64, b), dim3(256), 0, stream, A, first, W0, n, status);
+        T *cur = W0, *nxt = W1;
+        for (int k0 = 0; k0 < n; k0 += BGJ_PB) {
+            hipLaunchKernelGGL(matinv_bgj_panel<T>, dim3(b), dim3(threads), 0, stream, cur, nxt, Bbuf, rowsrc, pivots, n, k0, status);
+            hipLaunchKernelGGL(matinv_bgj_update<T>, dim3(g, g, b), dim3(256), 0, stream, cur, nxt, Bbuf, rowsrc, n, k0, status);
+            T *tmp = cur;
+            cur = nxt;
+            nxt = tmp;
+        }
+        hipLaunchKernelGGL(matinv_bgj_finish<T>, dim3(g, b), dim3(256), 0, stream, cur, X, first, pivots, info, n, status);
+    }
+    e = hipGetLastError();
+    hipError_t e2 = hipFreeAsync(ws, stream), e3 = hipFreeAsync(iws, stream);
+    return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
+}
+template hipError_t launch_gj_blocked<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
+template hipError_t launch_gj_blocked<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
+
+}  // namespace matinv

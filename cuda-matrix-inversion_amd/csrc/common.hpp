@@ -75,6 +75,11 @@ bool blocked_inverse_supports(int n);
 template <class T>
 hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 
+// blocked Gauss-Jordan with partial pivoting for large general matrices (blocked_gj_kernels.hip)
+bool blocked_gj_supports(int n);
+template <class T>
+hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+
 // GLOBAL family (global_kernels.hip): any n <= 1024, working copy in global memory
 template <class T>
 bool global_family_supports(int n);

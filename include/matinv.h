@@ -59,9 +59,10 @@ typedef enum {
                                   row broadcast through v_readlane; the pivoting path behind the tile family */
     MATINV_KERNEL_GLOBAL = 5,  /* any n <= 1024 (the reference's limit): one 1024-thread workgroup per matrix, working copy
                                   in global memory; the functional path for matrices that do not fit on chip */
-    MATINV_KERNEL_BLOCKED = 6  /* MATINV_ALGO_CHOLESKY, any n <= 1024: blocked right-looking Cholesky on a global-memory working
-                                  copy, two launches per 64-column panel over the whole batch, A^-1 = L^-T L^-1 as one symmetric
-                                  product; the automatic choice for SPD inversions beyond n = 128 */
+    MATINV_KERNEL_BLOCKED = 6  /* any n <= 1024, global-memory working copies, two launches per panel over the whole batch.
+                                  MATINV_ALGO_CHOLESKY: blocked right-looking Cholesky, A^-1 = L^-T L^-1 as one symmetric product
+                                  (automatic beyond n = 128). MATINV_ALGO_GAUSS_JORDAN: blocked Gauss-Jordan with partial
+                                  pivoting, panel of 32 columns eliminated with one thread per row (automatic beyond the LDS limit) */
 } matinv_kernel;
 
 /* Invert `batch` matrices that are already resident in device memory.

@@ -41,7 +41,7 @@ def test_kernel_selection_is_pure_host_logic():
     api = pkg("api")
     for n in (1, 8, 16, 32, 64, 128):
         k = api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, n)
-        assert k in (api.KERNEL_LDS, api.KERNEL_ROWLANE, api.KERNEL_TILE)
+        assert k in (api.KERNEL_ROWLANE, api.KERNEL_TILE)
         assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, n).startswith("matinv_")
         assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, n) == api.KERNEL_TILE
         assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, n) == api.KERNEL_TILE
@@ -49,8 +49,8 @@ def test_kernel_selection_is_pure_host_logic():
     assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, 1024) == api.KERNEL_BLOCKED
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 128) == "matinv_gj_tile4_f32<8, true, 4, false>"
     assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 100) == "matinv_gj_tile4_f64<7, false, 4, true>"
-    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 512) == api.KERNEL_GLOBAL
-    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 150) == api.KERNEL_LDS
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 512) == api.KERNEL_BLOCKED
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 150) == api.KERNEL_BLOCKED
     with pytest.raises(pkg("_lib").MatinvError):
         api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 4096)
 

@@ -232,6 +232,36 @@ def test_cholesky_large_n_blocked(n, batch, dtype):
     assert np.array_equal(g, g.transpose(0, 2, 1))     # mirrored on write: exactly symmetric
 
 
+@pytest.mark.parametrize("n,batch,dtype", [(138, 6, "f64"), (200, 4, "f64"), (333, 3, "f64"), (512, 2, "f32"), (1000, 2, "f32"), (1024, 1, "f64")])
+def test_gauss_jordan_large_n_blocked_general(n, batch, dtype):
+    """General (non-symmetric, needs row exchanges) matrices beyond the LDS limit: blocked Gauss-Jordan with partial
+    pivoting over global-memory working copies (blocked_gj_kernels.hip); ragged panels and tiles, a structurally singular
+    item (zero column: info = that column, NaN result, neighbours untouched), both precisions, and the explicit GLOBAL
+    family as a second opinion."""
+    a = general_batch(n, batch, seed=70 + n)
+    want, _ = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT)
+    cond = max(np.linalg.cond(m) for m in as_mats(a, n))
+    bad = batch - 1
+    sing = a.reshape(batch, n, n).copy()
+    if batch > 1:
+        sing[bad, n // 2, :] = 0.0                        # column n/2 of the last item (memory is [k, col, row])
+    np_t = np.float64 if dtype == "f64" else np.float32
+    code = api.F64 if dtype == "f64" else api.F32
+    assert api.select_kernel(GJ, code, n) == api.KERNEL_BLOCKED
+    got, info = gpu_inverse(sing.reshape(-1).astype(np_t), n, GJ, want_info=True)
+    got = got.astype(np.float64)
+    ok = batch - 1 if batch > 1 else 1
+    if batch > 1:
+        assert info.tolist() == [0] * (batch - 1) + [n // 2 + 1]
+        assert np.isnan(as_mats(got, n)[bad]).all()
+    g, w_ = as_mats(got, n)[:ok], as_mats(want, n)[:ok]
+    err = (np.linalg.norm((g - w_).reshape(ok, -1), axis=1) / np.linalg.norm(w_.reshape(ok, -1), axis=1)).max()
+    assert err < (max(1e-10, 1e-15 * cond * n) if dtype == "f64" else max(1e-3, 1e-6 * cond))
+    if n <= 333 and dtype == "f64":
+        ref = gpu_inverse(a[: n * n].copy(), n, GJ, api.KERNEL_GLOBAL)
+        assert rel_err(ref, got[: n * n], n) < max(1e-10, 1e-15 * cond * n)
+
+
 def test_large_n_singular_and_fp32():
     n = 160
     a = spd_batch(n, 3, seed=1).reshape(3, n, n)
