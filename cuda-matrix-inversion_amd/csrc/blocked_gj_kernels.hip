@@ -14,6 +14,8 @@
 // and one last launch that undoes the row swaps as column swaps while copying into the caller's buffer. 2 n / 32 + 2
 // launches replace the reference's 3 n (pivotRow / normalizeRow / transform_matrix, batched_invert.cu:84-95); a batch
 // of few large matrices still fills the chip in the update, which is where the 2 n^3 flops are.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace matinv {
@@ -236,6 +238,17 @@ __global__ __launch_bounds__(256) void matinv_bgj_finish(const T *W, BatchRef<T>
     if (info && blockIdx.x == 0 && t == 0) info[first + item] = bad;
 }
 
+// workspace cap of the blocked paths (bytes); MATINV_BLOCKED_WS_MB overrides the 4 GiB default (tests use it to force chunking)
+size_t blocked_workspace_cap()
+{
+    static const size_t cap = []() {
+        const char *s = getenv("MATINV_BLOCKED_WS_MB");
+        const long mb = s && *s ? atol(s) : 0;
+        return mb > 0 ? (size_t)mb << 20 : (size_t)4 << 30;
+    }();
+    return cap;
+}
+
 bool blocked_gj_supports(int n) { return n >= 1 && n <= 1024; }
 
 template <class T>
@@ -244,7 +257,7 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
     if (!blocked_gj_supports(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     const size_t per_item = (2 * (size_t)n * n + (size_t)BGJ_PB * n) * sizeof(T);
-    size_t chunk = (size_t)(4ull << 30) / per_item;  // bounded workspace, grid.y / grid.z limit
+    size_t chunk = blocked_workspace_cap() / per_item;  // bounded workspace, grid.y / grid.z limit
     if (chunk < 1) chunk = 1;
     if (chunk > 65535) chunk = 65535;
     if (chunk > batch) chunk = batch;

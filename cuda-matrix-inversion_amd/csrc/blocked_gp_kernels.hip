@@ -276,7 +276,7 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     if (batch == 0) return hipSuccess;
     const int ld = 2 * n;
     // chunks: grid.y / grid.z limit and a bounded workspace (<= 4 GiB)
-    size_t chunk = (size_t)(4ull << 30) / ((size_t)ld * n * sizeof(T));
+    size_t chunk = blocked_workspace_cap() / ((size_t)ld * n * sizeof(T));
     if (chunk < 1) chunk = 1;
     if (chunk > 65535) chunk = 65535;
     if (chunk > batch) chunk = batch;
