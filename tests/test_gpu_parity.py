@@ -405,9 +405,10 @@ def test_strided_batch_and_in_place():
                                   "inverse_cholesky_batched_gpu", "inverse_cholesky_mm_batched_gpu",
                                   "inverse_cholesky_mm2_batched_gpu", "inverse_cholesky_stride_batched_gpu"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_reference_host_pointer_family(name, dtype):
-    """inverse_bench's call sites (src/inverse_bench.c:144,168,191,214): host arrays in, host arrays out."""
-    n, batch = 32, 50
+@pytest.mark.parametrize("n,batch", [(32, 50), (128, 9), (150, 5)])
+def test_reference_host_pointer_family(name, dtype, n, batch):
+    """inverse_bench's call sites (src/inverse_bench.c:144,168,191,214): host arrays in, host arrays out; the reference's
+    sweep sizes up to 128 (`make run-inverse-bench`) and one size beyond (blocked families)."""
     a = spd_batch(n, batch, seed=21).astype(dtype)
     keep = a.copy()
     out = np.zeros_like(a)
