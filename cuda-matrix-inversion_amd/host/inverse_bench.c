@@ -91,7 +91,9 @@ int main(int argc, char const *argv[])
         {"lu_cuda_batched_gpu", inverse_lu_cuda_batched_gpu},
     };
     cublasHandle_t handle = NULL; /* was cublasCreate(&handle), :132 */
-    for (size_t g = 0; g < sizeof gpu / sizeof gpu[0]; ++g) {
+    const char *skip = getenv("MATINV_SKIP_GPU"); /* CPU lines only, for a host without an MI355X (like gauss_bench) */
+    const bool skip_gpu = skip && *skip && *skip != '0';
+    for (size_t g = 0; !skip_gpu && g < sizeof gpu / sizeof gpu[0]; ++g) {
         TIMER_INIT(gpu_call) TIMER_ACC_INIT(gpu_call)
         for (int rep = 0; rep < numReps; ++rep) {
             memcpy(workspace, a, count * sizeof(DataType));

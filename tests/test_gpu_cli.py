@@ -61,3 +61,25 @@ def test_detailed_logging_lines():
         assert k in keys, (k, keys)
     f = [ln for ln in p.stdout.splitlines() if ln.startswith("inverse_gauss_batched_gpu_ker,")][0].strip().split(",")
     assert f[1] == "100" and f[2] == "8" and float(f[3]) >= 0 and int(f[4]) >= 0
+
+
+@pytest.mark.parametrize("n,k", [(64, 40), (128, 12)])
+def test_sweep_sizes_missing_from_the_reference_tree(tmp_path, n, k):
+    """The reference's `make run-inverse-bench` / `run-gauss-bench` sweeps go up to 128x128, but its 64 / 128 fixtures are
+    absent (.MISSING_LARGE_BLOBS): generate them (tools/generate_fixtures.py) and run both CLIs, both DataTypes."""
+    import sys
+    gen = os.path.join(ROOT, "tools", "generate_fixtures.py")
+    inv_dir, gp_dir = str(tmp_path / f"inverse_{k}_{n}x{n}"), str(tmp_path / f"gaussian_{k}_{n}x{n}")
+    subprocess.run([sys.executable, gen, "inverse", inv_dir, str(k), str(n)], check=True)
+    subprocess.run([sys.executable, gen, "gaussian", gp_dir, str(k), str(n)], check=True)
+    for exe, tol in (("inverse_bench", 1e-12), ("inverse_bench_f32", 2e-4)):
+        lines = run(exe, inv_dir, "2", "2", "-csv")
+        assert [ln.split()[3] for ln in lines] == ["lu_blas_cpu", "lu_blas_omp_cpu", "chol_gpu", "chol_mm2_gpu",
+                                                    "gauss_batched_gpu", "lu_cuda_batched_gpu"]
+        for ln in lines:
+            assert ln.split()[:3] == [str(2 * k), str(n), "2"] and float(ln.split()[7]) < tol, ln
+    for exe, tol in (("gauss_bench", 1e-12), ("gauss_bench_f32", 2e-5)):
+        lines = run(exe, gp_dir, "2", "2", "-csv")
+        assert [ln.split()[3] for ln in lines] == ["means_cpu", "variances_cpu", "means_gpu", "variances_gpu"]
+        for ln in lines:
+            assert float(ln.split()[7]) < tol, ln

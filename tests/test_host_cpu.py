@@ -112,3 +112,29 @@ def test_cli_usage_and_bad_fixture_are_fatal(host, tmp_path):
     (tmp_path / "aInv.mats").write_text("1 2 2\n1 0\n0 1\n")
     p = _run("inverse_bench", str(tmp_path), "1", "1")
     assert p.returncode != 0 and "number of matrices in files not matching" in p.stderr
+
+
+def test_synthetic_fixture_generator_feeds_both_clis(host, tmp_path):
+    """tools/generate_fixtures.py (the reference's MATLAB generators, whose 64x64 / 128x128 outputs are missing from its
+    tree) -> `.mats` directories both command lines accept; CPU lines agree with numpy's expected values to round-off."""
+    import subprocess
+    import sys
+    gen = os.path.join(ROOT, "tools", "generate_fixtures.py")
+    inv_dir, gp_dir = str(tmp_path / "inverse_6_40x40"), str(tmp_path / "gaussian_5_24x24")
+    subprocess.run([sys.executable, gen, "inverse", inv_dir, "6", "40"], check=True)
+    subprocess.run([sys.executable, gen, "gaussian", gp_dir, "5", "24", "--seed", "7"], check=True)
+    mats = pkg("mats")
+    a, k, m, n = mats.read_mats(os.path.join(inv_dir, "a.mats"))
+    ainv, *_ = mats.read_mats(os.path.join(inv_dir, "aInv.mats"))
+    assert (k, m, n) == (6, 40, 40)
+    A = a.reshape(k, n, n).transpose(0, 2, 1)
+    assert np.allclose(A, A.transpose(0, 2, 1)) and np.abs(A @ ainv.reshape(k, n, n).transpose(0, 2, 1) - np.eye(n)).max() < 1e-13
+    lines = _run("inverse_bench", inv_dir, "2", "3", "-csv", env={"MATINV_SKIP_GPU": "1"}).stdout.strip().splitlines()
+    assert [ln.split()[3] for ln in lines] == ["lu_blas_cpu", "lu_blas_omp_cpu"]
+    assert all(ln.split()[:3] == ["18", "40", "2"] and float(ln.split()[7]) < 1e-12 for ln in lines)
+    lines = _run("gauss_bench", gp_dir, "2", "1", "-csv", env={"MATINV_SKIP_GPU": "1"}).stdout.strip().splitlines()
+    assert [ln.split()[3] for ln in lines] == ["means_cpu", "variances_cpu"]
+    assert all(float(ln.split()[7]) < 1e-13 for ln in lines)
+    short = str(tmp_path / "short")
+    subprocess.run([sys.executable, gen, "inverse", short, "2", "8", "--digits", "5"], check=True)
+    assert len(open(os.path.join(short, "a.mats")).read().split()[3]) <= 7   # dlmwrite-like short decimals
