@@ -14,6 +14,10 @@
 // and one last launch that undoes the row swaps as column swaps while copying into the caller's buffer. 2 n / 32 + 2
 // launches replace the reference's 3 n (pivotRow / normalizeRow / transform_matrix, batched_invert.cu:84-95); a batch
 // of few large matrices still fills the chip in the update, which is where the 2 n^3 flops are.
+// (Measured and not used: 64-column panels for n <= 512, which halve the passes over the working copies. The panel kernel
+// then needs 64 panel entries per thread -- 256 VGPRs and scratch in fp64 -- and runs 64 dependent column steps per launch:
+// fp64 130^2 8.5e5 -> 6.1e5 inv/s, 256^2 2.4e5 -> 2.3e5, 512^2 3.4e4 -> 3.6e4; fp32 512^2 5.5e4 -> 7.1e4; and the file took
+// 3m50s to compile.)
 #include <stdlib.h>
 
 #include "common.hpp"
