@@ -398,7 +398,7 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             const char *s = getenv("MATINV_GP_BLOCKED");  // A/B switch for profiling; default on
             return !(s && *s == '0');
         }();
-        if (use_blocked && batch <= 65535) {
+        if (use_blocked) {
             hipError_t eb = launch_gp_blocked<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
                                                  static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
                                                  static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,

@@ -166,27 +166,35 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
 {
     if (n < 1 || n > 4096) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    if (batch > 65535) return hipErrorInvalidValue;  // grid.y / grid.z limit; callers split larger batches
     const int ld = n + 2;
+    // chunks: grid.y / grid.z limit and a bounded workspace
+    size_t chunk = blocked_workspace_cap() / ((size_t)ld * n * sizeof(T));
+    if (chunk < 1) chunk = 1;
+    if (chunk > 65535) chunk = 65535;
+    if (chunk > batch) chunk = batch;
     T *W = nullptr;
     int *status = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&W), batch * (size_t)ld * n * sizeof(T), stream);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&W), chunk * (size_t)ld * n * sizeof(T), stream);
     if (e != hipSuccess) return e;
-    e = hipMallocAsync(reinterpret_cast<void **>(&status), batch * sizeof(int), stream);
+    e = hipMallocAsync(reinterpret_cast<void **>(&status), chunk * sizeof(int), stream);
     if (e != hipSuccess) { (void)hipFreeAsync(W, stream); return e; }
-    hipLaunchKernelGGL(matinv_bgp_init<T>, dim3(64, (unsigned)batch), dim3(BGP_THREADS), 0, stream, As, Bs, Cs, Ds, W, n, status);
-    for (int k0 = 0; k0 < n; k0 += BGP_PB) {
-        const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
-        const unsigned chunks = (unsigned)((ld - (k0 + pb) + BGP_THREADS - 1) / BGP_THREADS);  // >= 1: the border rows
-        hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, (unsigned)batch), dim3(BGP_THREADS), 0, stream, W, n, ld, ld, k0, status);
-        const int rem_cols = n - (k0 + BGP_PB), rem_rows = ld - (k0 + BGP_PB);
-        if (rem_cols > 0) {
-            const unsigned gx = (rem_cols + BGP_TILE - 1) / BGP_TILE, gy = (rem_rows + BGP_TILE - 1) / BGP_TILE;
-            hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, (unsigned)batch), dim3(BGP_THREADS), 0, stream, W, n, ld, ld, k0, status);
+    for (size_t first = 0; first < batch; first += chunk) {
+        const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
+        const T *a_ = As + first * n, *B_ = Bs + first * (size_t)n * n, *c_ = Cs + first * n, *d_ = Ds ? Ds + first * n : nullptr;
+        hipLaunchKernelGGL(matinv_bgp_init<T>, dim3(64, b), dim3(BGP_THREADS), 0, stream, a_, B_, c_, d_, W, n, status);
+        for (int k0 = 0; k0 < n; k0 += BGP_PB) {
+            const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
+            const unsigned chunks = (unsigned)((ld - (k0 + pb) + BGP_THREADS - 1) / BGP_THREADS);  // >= 1: the border rows
+            hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, n, ld, ld, k0, status);
+            const int rem_cols = n - (k0 + BGP_PB), rem_rows = ld - (k0 + BGP_PB);
+            if (rem_cols > 0) {
+                const unsigned gx = (rem_cols + BGP_TILE - 1) / BGP_TILE, gy = (rem_rows + BGP_TILE - 1) / BGP_TILE;
+                hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, b), dim3(BGP_THREADS), 0, stream, W, n, ld, ld, k0, status);
+            }
         }
+        hipLaunchKernelGGL(matinv_bgp_finish<T>, dim3(b), dim3(BGP_THREADS), 0, stream, W, (Ds || !Es) ? nullptr : Es + first,
+                           out + first, info ? info + first : nullptr, n, status);
     }
-    hipLaunchKernelGGL(matinv_bgp_finish<T>, dim3((unsigned)batch), dim3(BGP_THREADS), 0, stream, W, Ds ? nullptr : Es, out, info,
-                       n, status);
     e = hipGetLastError();
     hipError_t e2 = hipFreeAsync(W, stream), e3 = hipFreeAsync(status, stream);
     return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);

@@ -283,6 +283,16 @@ for algo, oalgo, a in ((api.ALGO_GAUSS_JORDAN, oracle.ALGO_GJ_PIVOT, general_bat
     assert not info.cpu().numpy().any()
     cond = max(np.linalg.cond(m) for m in a.reshape(batch, n, n))
     assert rel_err(got, want, n) < max(1e-10, 1e-15 * cond * n), algo
+n, batch = 210, 11  # pipeline beyond the LDS limit: (n + 2) n doubles per item = 0.36 MB -> chunks of 5
+rng = np.random.default_rng(3)
+B = spd_batch(n, batch, seed=4)
+va, vc, vd = (rng.random(batch * n) for _ in range(3))
+ve = rng.random(batch)
+t = [torch.from_numpy(x).cuda() for x in (va, B, vc, vd, ve)]
+m = api.calcluateMean(n, t[0], t[1], t[2], t[3]).cpu().numpy()
+v = api.calcluateVariance(n, t[0], t[1], t[2], t[4]).cpu().numpy()
+assert np.abs(m - oracle.mean_batched(va, B, vc, vd, n)).max() < 1e-10
+assert np.abs(v - oracle.variance_batched(va, B, vc, ve, n)).max() < 1e-10
 print("CHUNKED-OK")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MATINV_BLOCKED_WS_MB="2")
