@@ -75,6 +75,9 @@ __device__ __forceinline__ void prep_operands(typename TileGeo<T>::vec4 (&acc)[N
 }
 
 // One matrix per wavefront; see the file header. T = double or float.
+// (Tried, not kept: letting a matrix that has already failed the acceptance test skip the remaining block steps through
+// nested scalar branches after every fourth step -- no loop exit, accumulators dead on the rejected path. hipcc answers the
+// control flow with 256 VGPRs + 344 B of scratch in the headline kernel instead of 212 and none.)
 // (Tried and measured, not kept: streaming half of the wave's NEXT matrix into LDS with global_load_lds_dwordx4 during
 // the elimination. The exposed time per matrix is load LATENCY, not bytes: 1.651 ms with, 1.645 ms without at 100 k x 64^2.)
 template <class T, int NT, bool FULL, bool LOOKAHEAD>
