@@ -75,6 +75,10 @@ bool blocked_inverse_supports(int n);
 template <class T>
 hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 
+// rounds of resident workgroups in the grids of the MFMA-tile kernels (each workgroup strides over the batch);
+// MATINV_TILE_GRID_MULT overrides the default for A/B measurements (tile_kernels.hip)
+unsigned tile_grid_rounds();
+
 // blocked Gauss-Jordan with partial pivoting for large general matrices (blocked_gj_kernels.hip)
 bool blocked_gj_supports(int n);
 size_t blocked_workspace_cap();  // bytes; MATINV_BLOCKED_WS_MB overrides the 4 GiB default

@@ -184,7 +184,7 @@ hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T 
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
     const int nt = (n + 15) / 16;
-    const unsigned grid = (unsigned)(batch < 256u * 8u * 4u ? batch : 256u * 8u * 4u);
+    const unsigned grid = (unsigned)(batch < 256u * 8u * tile_grid_rounds() ? batch : 256u * 8u * tile_grid_rounds());
     const unsigned b = (unsigned)batch;
 #define GP_LAUNCH(NT_)                                                                                                \
     if constexpr (sizeof(T) == 8) {                                                                                   \

@@ -331,7 +331,7 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
     const int nt = (n + 15) / 16;
-    const unsigned grid = (unsigned)(batch < 256u * 3u * 4u ? batch : 256u * 3u * 4u);
+    const unsigned grid = (unsigned)(batch < 256u * 3u * tile_grid_rounds() ? batch : 256u * 3u * tile_grid_rounds());
     const unsigned b = (unsigned)batch;
 #define T4_LAUNCH(NT_)                                                                                                \
     if constexpr (sizeof(T) == 8) {                                                                                   \
@@ -388,7 +388,7 @@ hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T
     if (e != hipSuccess) return e;
     const int nt = (n + 15) / 16;
     const unsigned occ = sizeof(T) == 8 ? 2u : 3u;
-    const unsigned grid = (unsigned)(batch < 256u * occ * 4u ? batch : 256u * occ * 4u);
+    const unsigned grid = (unsigned)(batch < 256u * occ * tile_grid_rounds() ? batch : 256u * occ * tile_grid_rounds());
     const unsigned b = (unsigned)batch;
 #define GP4_LAUNCH(NT_)                                                                                               \
     if constexpr (sizeof(T) == 8)                                                                                     \
