@@ -170,10 +170,12 @@ hipError_t launch_gj_row_worklist(int n, BatchRef<const T> A, BatchRef<T> X, con
                                   int *info, hipStream_t stream)
 {
     if (!row_family_supports<T>(n)) return hipErrorInvalidValue;
+    // the list length is only known on the device: a few rounds of resident blocks; blocks beyond the list exit at once
+    const unsigned wl_rounds = tile_grid_rounds() < 8u ? tile_grid_rounds() : 8u;
     if (n <= 32)
-        hipLaunchKernelGGL((matinv_gj_row_worklist<T, 32>), dim3(512), dim3(256), 0, stream, A, X, info, n, work_count, work_list);
+        hipLaunchKernelGGL((matinv_gj_row_worklist<T, 32>), dim3(512 * wl_rounds), dim3(256), 0, stream, A, X, info, n, work_count, work_list);
     else
-        hipLaunchKernelGGL((matinv_gj_row_worklist<T, 64>), dim3(512), dim3(256), 0, stream, A, X, info, n, work_count, work_list);
+        hipLaunchKernelGGL((matinv_gj_row_worklist<T, 64>), dim3(512 * wl_rounds), dim3(256), 0, stream, A, X, info, n, work_count, work_list);
     return hipGetLastError();
 }
 template <class T>
@@ -182,7 +184,9 @@ hipError_t launch_gj_row(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch
     if (!row_family_supports<T>(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     const size_t blocks = (batch + 3) / 4;
-    const unsigned grid = (unsigned)(blocks < 256u * 2u ? blocks : 256u * 2u);  // resident: 2 blocks of 4 waves per CU
+    // 2 blocks of 4 waves are resident per CU; like the tile kernels (tile_grid_rounds) many rounds beat a static stride
+    const unsigned cap = 256u * 2u * tile_grid_rounds();
+    const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
     if (n <= 32) hipLaunchKernelGGL((matinv_gj_row<T, 32>), dim3(grid), dim3(256), 0, stream, A, X, info, n, (unsigned)batch);
     else hipLaunchKernelGGL((matinv_gj_row<T, 64>), dim3(grid), dim3(256), 0, stream, A, X, info, n, (unsigned)batch);
     return hipGetLastError();
