@@ -410,6 +410,26 @@ def test_strided_batch_and_in_place():
     assert rel_err(d_in.cpu().numpy().reshape(batch, stride)[:, : n * n].reshape(-1), want, n) < 1e-10
 
 
+@pytest.mark.parametrize("n,dtype", [(64, np.float64), (64, np.float32), (32, np.float64), (128, np.float64), (128, np.float32)])
+def test_odd_stride_breaks_vector_alignment(n, dtype):
+    """Strides that are odd in elements put every other matrix on an address that is only element-aligned: the kernels'
+    8- and 16-byte vector accesses must still be correct (and must not touch the gap), for both algorithms."""
+    batch, stride = 7, n * n + 1
+    a = spd_batch(n, batch, seed=13).astype(dtype).reshape(batch, n * n)
+    buf = np.full((batch, stride), 123.0, dtype=dtype)
+    buf[:, : n * n] = a
+    want, _ = oracle.inverse_batched(a.astype(np.float64).reshape(-1), n)
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    for algo in (GJ, CH):
+        d_in = dev(buf.reshape(-1))
+        d_out = torch.full_like(d_in, -5.0)
+        api.inverse_batched(d_in, n, algo, out=d_out, batch=batch, stride=stride)
+        res = d_out.cpu().numpy().reshape(batch, stride)
+        assert rel_err(res[:, : n * n].reshape(-1).astype(np.float64), want, n) < tol
+        assert (res[:, n * n:] == -5.0).all(), "padding between matrices was written"
+        assert torch.equal(d_in.cpu(), torch.from_numpy(buf.reshape(-1)))
+
+
 # ------------------------------------------------------------------ reference-named entry points (C symbols)
 @pytest.mark.parametrize("name", ["inverse_gauss_batched_gpu", "inverse_lu_cuda_batched_gpu",
                                   "inverse_cholesky_batched_gpu", "inverse_cholesky_mm_batched_gpu",
