@@ -113,7 +113,7 @@ __global__ __launch_bounds__(1024) void matinv_bgj_panel(const T *Win, T *Wout, 
                 const int oi = s_idx[w];
                 if (ob > best) { best = ob; p = oi; }  // equal maxima: the lower wave (lower rows) keeps it
             }
-            if (!(best > 0)) {  // zero or NaN column: singular (block-uniform)
+            if (!(best > 0) || best > max_finite<T>()) {  // zero, NaN or infinite column: no usable pivot (block-uniform)
                 if (t == 0) status[item] = k + 1;
                 return;
             }

@@ -59,7 +59,7 @@ __device__ __forceinline__ int chol_factor_lds(T *a, int ld, int n, int nrows)
 #pragma unroll
         for (int k = 0; k < CHOL_PB; ++k) {
             const T d = l[k][k];
-            if (!(d > 0) && bad == 0) bad = k0 + k + 1;
+            if ((!(d > 0) || d > max_finite<T>()) && bad == 0) bad = k0 + k + 1;  // non-positive, NaN or infinite pivot
             T sd, rs;
             sqrt_and_rsqrt(d, sd, rs);
             l[k][k] = sd, inv[k] = rs;

@@ -32,6 +32,12 @@ struct BatchRef {
 };
 
 template <class T>
+__device__ __forceinline__ T max_finite();
+template <>
+__device__ __forceinline__ double max_finite<double>() { return 1.7976931348623157e308; }
+template <>
+__device__ __forceinline__ float max_finite<float>() { return 3.402823466e38f; }
+template <class T>
 __device__ __forceinline__ T nan_of();
 template <>
 __device__ __forceinline__ double nan_of<double>() { return __longlong_as_double(0x7ff8000000000000LL); }

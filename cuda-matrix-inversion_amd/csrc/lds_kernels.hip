@@ -139,7 +139,7 @@ __device__ __forceinline__ void gj_lds_one(const T *A, T *X, int *info_slot, int
                     int oi = s_red_idx[w];
                     if (ob > best) { best = ob; p = oi; }  // equal maxima: the lower wave (lower rows) keeps it
                 }
-                if (!(best > 0)) {  // zero or NaN column: singular (block-uniform)
+                if (!(best > 0) || best > max_finite<T>()) {  // zero, NaN or infinite column: no usable pivot (block-uniform)
                     if (info_slot && t == 0) *info_slot = k + 1;
                     fill_nan(X, n);
                     return;

@@ -410,6 +410,29 @@ def test_strided_batch_and_in_place():
     assert rel_err(d_in.cpu().numpy().reshape(batch, stride)[:, : n * n].reshape(-1), want, n) < 1e-10
 
 
+@pytest.mark.parametrize("n", [8, 16, 32, 64, 100, 128, 200])
+def test_nan_and_inf_inputs_are_reported_not_propagated(n):
+    """A NaN or an Inf inside one matrix: that matrix is reported (info != 0, result all NaN) by every family on the
+    automatic path, the other matrices of the batch are inverted as usual."""
+    batch = 6
+    a = spd_batch(n, batch, seed=17).reshape(batch, n, n)
+    want, _ = oracle.inverse_batched(a.reshape(-1), n)
+    a[1, n // 2, n // 3] = np.nan
+    a[1, n // 3, n // 2] = np.nan
+    a[4, 0, 0] = np.inf
+    ok = [0, 2, 3, 5]
+    for algo in (GJ, CH):
+        d_in = dev(a.reshape(-1))
+        t_info = torch.full((batch,), -7, dtype=torch.int32, device="cuda")
+        got = api.inverse_batched(d_in, n, algo, info=t_info, batch=batch).cpu().numpy()
+        info = t_info.cpu().numpy()
+        assert np.array_equal(d_in.cpu().numpy(), a.reshape(-1), equal_nan=True), "input batch was modified"
+        assert info[1] != 0 and info[4] != 0 and not info[ok].any(), (algo, info)
+        g = as_mats(got, n)
+        assert np.isnan(g[1]).all() and np.isnan(g[4]).all()
+        assert rel_err(g[ok].reshape(-1), as_mats(want, n)[ok].reshape(-1), n) < 1e-10
+
+
 @pytest.mark.parametrize("n,dtype", [(64, np.float64), (64, np.float32), (32, np.float64), (128, np.float64), (128, np.float32)])
 def test_odd_stride_breaks_vector_alignment(n, dtype):
     """Strides that are odd in elements put every other matrix on an address that is only element-aligned: the kernels'
