@@ -59,6 +59,8 @@ int select_auto(int algo, int n)
         if (rowlane_family_supports<T>(n)) return MATINV_KERNEL_ROWLANE;
         if (tile_family_supports<T>(n)) return MATINV_KERNEL_TILE;
         if (blocked_gj_supports(n)) return MATINV_KERNEL_BLOCKED;  // beyond n = 128 it beats the LDS kernel at every size measured
+    } else if (rowlane_family_supports<T>(n)) {
+        return MATINV_KERNEL_ROWLANE;  // several SPD matrices per wavefront
     } else if (spd_tile_supports<T>(n)) {
         return MATINV_KERNEL_TILE;
     } else if (blocked_inverse_supports(n)) {
@@ -95,9 +97,10 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
                                                : launch_chol_lds<T>(n, A, X, batch, dInfo, stream, chol_phases);
         break;
     case MATINV_KERNEL_ROWLANE:
-        if (algo != MATINV_ALGO_GAUSS_JORDAN || !rowlane_family_supports<T>(n))
-            return fail(MATINV_ERR_UNSUPPORTED, "rowlane family serves Gauss-Jordan with n <= 16 only (n=%d)", n);
-        e = launch_gj_rowlane<T>(n, A, X, batch, dInfo, stream);
+        if (!rowlane_family_supports<T>(n) || (algo == MATINV_ALGO_CHOLESKY && chol_phases != 7))
+            return fail(MATINV_ERR_UNSUPPORTED, "rowlane family serves full inversions with n <= 16 only (n=%d)", n);
+        e = (algo == MATINV_ALGO_CHOLESKY) ? launch_spd_rowlane<T>(n, A, X, batch, dInfo, stream)
+                                           : launch_gj_rowlane<T>(n, A, X, batch, dInfo, stream);
         break;
     case MATINV_KERNEL_TILE:
         if (algo == MATINV_ALGO_CHOLESKY) {
@@ -518,7 +521,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     if (kernel == MATINV_KERNEL_AUTO) kernel = matinv_select_kernel(algo, dtype, n);
     switch (kernel) {
     case MATINV_KERNEL_LDS: return algo == MATINV_ALGO_CHOLESKY ? name_chol_lds(f64) : name_gj_lds(f64);
-    case MATINV_KERNEL_ROWLANE: return name_gj_rowlane(f64, n);
+    case MATINV_KERNEL_ROWLANE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_rowlane(f64, n) : name_gj_rowlane(f64, n);
     case MATINV_KERNEL_TILE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_tile(f64, n) : name_gj_tile(f64, n);
     case MATINV_KERNEL_ROW: return name_gj_row(f64, n);
     case MATINV_KERNEL_GLOBAL: return algo == MATINV_ALGO_CHOLESKY ? name_chol_global(f64) : name_gj_global(f64);

@@ -68,6 +68,10 @@ bool lds_family_supports(int n);
 
 template <class T>
 hipError_t launch_gj_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+// the same kernel as the Cholesky entry point for n <= 16 (lower triangle only, natural positive pivots)
+template <class T>
+hipError_t launch_spd_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+const char *name_spd_rowlane(bool f64, int n);
 template <class T>
 bool rowlane_family_supports(int n);
 

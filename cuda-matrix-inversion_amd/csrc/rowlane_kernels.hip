@@ -208,7 +208,13 @@ constexpr int rowlane_occupancy(size_t elem, int np, bool full)
     return elem == 8 ? (np == 16 ? (full ? 3 : 2) : (full ? 5 : 4)) : (np == 16 ? (full ? 5 : 4) : 6);
 }
 
-template <class T, int NP, bool FULL>
+// SPD = the Cholesky entry point for n <= 16 (the reference benchmarks its Cholesky kernels at 8x8 and 16x16): the same
+// elimination in natural order -- no search, no multiplier test: on SPD input every pivot is positive and the sweep is
+// stable --, only the LOWER triangle is USED (the load stays the coalesced full-matrix one; every lane then replaces its
+// upper entries by the mirrored lower ones through a padded LDS tile of its wave: 2 LDS accesses per element against an
+// uncoalesced second address pattern that cost 40 % at n = 16) and a pivot that is not positive marks the matrix as not
+// positive definite (info = that column, as the Cholesky factorisation would).
+template <class T, int NP, bool FULL, bool SPD = false>
 __global__ __launch_bounds__(ROWLANE_THREADS, rowlane_occupancy(sizeof(T), NP, FULL)) void matinv_gj_rowlane(BatchRef<const T> Ain, BatchRef<T> Xout, int *info,
                                                                      int n_rt, unsigned batch)
 {
@@ -221,6 +227,8 @@ __global__ __launch_bounds__(ROWLANE_THREADS, rowlane_occupancy(sizeof(T), NP, F
     const unsigned wave_stride = gridDim.x * waves_per_block;
     const unsigned n_waves = (batch + GPW - 1) / GPW;
 
+    __shared__ T sym_tile[SPD ? (ROWLANE_THREADS / 64) * 64 * (NP + 1) : 1];
+    T *tile = sym_tile + (SPD ? (threadIdx.x >> 6) * 64 * (NP + 1) : 0);
     const bool row_in = FULL || i < n;
     // Software prefetch: the matrices of the wave's NEXT grid-stride iteration are loaded into a second register set
     // before the current ones are eliminated, so their HBM latency hides behind ~600 VALU instructions instead of being
@@ -245,6 +253,20 @@ __global__ __launch_bounds__(ROWLANE_THREADS, rowlane_occupancy(sizeof(T), NP, F
 #pragma unroll
         for (int c = 0; c < NP; ++c) a[c] = nxt[c];
         if (w + wave_stride < n_waves) load(w + wave_stride);
+        if (SPD) {  // upper triangle <- mirror of the lower one (whatever the caller left there is never used)
+#pragma unroll
+            for (int c = 0; c < NP; ++c)
+                if (c <= i) tile[lane * (NP + 1) + c] = a[c];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int c = 0; c < NP; ++c)
+                if (c > i) a[c] = tile[(g * NP + c) * (NP + 1) + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 
         int src = i;            // lane j: source column of output column j (composite of the undone row swaps)
         int bad = 0;            // k+1 of the first step without a usable pivot
@@ -264,8 +286,9 @@ __global__ __launch_bounds__(ROWLANE_THREADS, rowlane_occupancy(sizeof(T), NP, F
             T piv = bcast_lane<NP>(a[k], k);
             T inv = recip(piv);
             T negm = (i == k) ? (T)0 : -(a[k] * inv);
-            const bool viol = !(absval(negm) <= (T)ROWLANE_TAU);
-            if (__any(viol)) {
+            if (SPD && !(piv > 0) && bad == 0) bad = k + 1;  // not positive definite (NaN included)
+            const bool viol = !SPD && !(absval(negm) <= (T)ROWLANE_TAU);
+            if (!SPD && __any(viol)) {
                 // pivot search in column k over rows >= k of this lane's matrix
                 const unsigned key = (i >= k) ? mag_key(a[k]) : 0u;
                 const unsigned mx = group_max<NP>(key);
@@ -323,7 +346,7 @@ bool rowlane_family_supports(int n) { return n >= 1 && n <= 16; }
 template bool rowlane_family_supports<double>(int);
 template bool rowlane_family_supports<float>(int);
 
-template <class T, int NP, bool FULL>
+template <class T, int NP, bool FULL, bool SPD>
 static hipError_t launch_one(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
     const unsigned gpw = 64 / NP;
@@ -337,23 +360,43 @@ static hipError_t launch_one(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
     }();
     const unsigned resident = 256u * (per_cu ? per_cu : (unsigned)rowlane_occupancy(sizeof(T), NP, FULL));
     const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
-    hipLaunchKernelGGL((matinv_gj_rowlane<T, NP, FULL>), dim3(grid), dim3(ROWLANE_THREADS), 0, stream, A, X, info, n,
+    hipLaunchKernelGGL((matinv_gj_rowlane<T, NP, FULL, SPD>), dim3(grid), dim3(ROWLANE_THREADS), 0, stream, A, X, info, n,
                        (unsigned)batch);
     return hipGetLastError();
 }
 
-template <class T>
-hipError_t launch_gj_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+template <class T, bool SPD>
+static hipError_t launch_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
     if (!rowlane_family_supports<T>(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    if (n == 16) return launch_one<T, 16, true>(n, A, X, batch, info, stream);
-    if (n == 8) return launch_one<T, 8, true>(n, A, X, batch, info, stream);
-    if (n < 8) return launch_one<T, 8, false>(n, A, X, batch, info, stream);
-    return launch_one<T, 16, false>(n, A, X, batch, info, stream);
+    if (n == 16) return launch_one<T, 16, true, SPD>(n, A, X, batch, info, stream);
+    if (n == 8) return launch_one<T, 8, true, SPD>(n, A, X, batch, info, stream);
+    if (n < 8) return launch_one<T, 8, false, SPD>(n, A, X, batch, info, stream);
+    return launch_one<T, 16, false, SPD>(n, A, X, batch, info, stream);
+}
+template <class T>
+hipError_t launch_gj_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    return launch_rowlane<T, false>(n, A, X, batch, info, stream);
+}
+template <class T>
+hipError_t launch_spd_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    return launch_rowlane<T, true>(n, A, X, batch, info, stream);
 }
 template hipError_t launch_gj_rowlane<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
 template hipError_t launch_gj_rowlane<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
+template hipError_t launch_spd_rowlane<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
+template hipError_t launch_spd_rowlane<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
+
+const char *name_spd_rowlane(bool f64, int n)
+{
+    if (n == 16) return f64 ? "matinv_gj_rowlane<double, 16, true, true>" : "matinv_gj_rowlane<float, 16, true, true>";
+    if (n == 8) return f64 ? "matinv_gj_rowlane<double, 8, true, true>" : "matinv_gj_rowlane<float, 8, true, true>";
+    if (n < 8) return f64 ? "matinv_gj_rowlane<double, 8, false, true>" : "matinv_gj_rowlane<float, 8, false, true>";
+    return f64 ? "matinv_gj_rowlane<double, 16, false, true>" : "matinv_gj_rowlane<float, 16, false, true>";
+}
 
 const char *name_gj_rowlane(bool f64, int n)
 {

@@ -43,8 +43,8 @@ def test_kernel_selection_is_pure_host_logic():
         k = api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, n)
         assert k in (api.KERNEL_ROWLANE, api.KERNEL_TILE)
         assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, n).startswith("matinv_")
-        assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, n) == api.KERNEL_TILE
-        assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, n) == api.KERNEL_TILE
+        assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, n) == (api.KERNEL_ROWLANE if n <= 16 else api.KERNEL_TILE)
+        assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, n) == (api.KERNEL_ROWLANE if n <= 16 else api.KERNEL_TILE)
     assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, 129) == api.KERNEL_BLOCKED
     assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, 1024) == api.KERNEL_BLOCKED
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 128) == "matinv_gj_tile4_f32<8, true, 4, false>"

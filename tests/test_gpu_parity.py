@@ -82,7 +82,7 @@ def test_gj_general_needs_pivoting_fp64(n, family):
     assert rel_err(got, want, n) < max(1e-10, 1e-15 * cond * n)
 
 
-@pytest.mark.parametrize("family", ["auto", "lds", "tile"])
+@pytest.mark.parametrize("family", ["auto", "lds", "tile", "rowlane"])
 @pytest.mark.parametrize("n", SIZES)
 def test_cholesky_spd_fp64_vs_oracle(n, family):
     k = family_or_skip(family, CH, torch.float64, n)
@@ -96,7 +96,7 @@ def test_cholesky_spd_fp64_vs_oracle(n, family):
     assert np.array_equal(g, g.transpose(0, 2, 1)) or rel_err(g.transpose(0, 2, 1).reshape(-1), got, n) < 1e-14
 
 
-@pytest.mark.parametrize("n", [5, 16, 33, 64, 70, 96, 128])
+@pytest.mark.parametrize("n", [3, 5, 8, 12, 16, 33, 64, 70, 96, 128])
 def test_cholesky_reads_only_the_lower_triangle(n):
     """Garbage in the strict upper triangle must not change the result (both Cholesky families)."""
     a = spd_batch(n, 9, seed=7 + n).reshape(9, n, n)      # memory [k, col, row]
@@ -104,7 +104,7 @@ def test_cholesky_reads_only_the_lower_triangle(n):
     iu = np.triu_indices(n, 1)                              # (col, row) with col < row ... careful: memory is [col,row]
     dirty[:, iu[1], iu[0]] = 1e30                          # element (row=iu[0], col=iu[1]) with row < col: upper
     want, _ = oracle.inverse_batched(a.reshape(-1), n, oracle.ALGO_CHOLESKY)
-    for fam in ("lds", "tile"):
+    for fam in ("lds", "tile", "auto"):
         k = family_or_skip(fam, CH, torch.float64, n)
         got, info = gpu_inverse(dirty.reshape(-1), n, CH, k, want_info=True)
         assert not info.any()
@@ -121,7 +121,7 @@ def test_spd_general_not_diagonally_dominant(n):
     want, info = oracle.inverse_batched(a, n, oracle.ALGO_CHOLESKY)
     assert not info.any()
     cond = max(np.linalg.cond(m) for m in A)
-    for fam in ("lds", "tile"):
+    for fam in ("lds", "tile", "auto"):
         k = family_or_skip(fam, CH, torch.float64, n)
         got, ginfo = gpu_inverse(a, n, CH, k, want_info=True)
         assert not ginfo.any()
