@@ -368,6 +368,19 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
     if (batch > 0x7fffffffu) return fail(MATINV_ERR_ARG, "batch %zu exceeds the grid limit; split the call", batch);
     int rc = check_device();
     if (rc) return rc;
+    if (rowlane_family_supports<T>(n)) {
+        static const bool use_rowlane = []() {
+            const char *s = getenv("MATINV_GP_ROWLANE");  // A/B switch for profiling; default on
+            return !(s && *s == '0');
+        }();
+        if (use_rowlane) {
+            hipError_t er = launch_gp_rowlane<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
+                                                 variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
+                                                 static_cast<T *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
+            if (er != hipSuccess) return fail_hip(er, "kernel launch");
+            return MATINV_OK;
+        }
+    }
     {
         static const bool use_tile = []() {
             const char *s = getenv("MATINV_GP_TILE");  // A/B switch for profiling; default on

@@ -72,6 +72,10 @@ hipError_t launch_gj_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
 template <class T>
 hipError_t launch_spd_rowlane(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 const char *name_spd_rowlane(bool f64, int n);
+// fused GP scalars on the same kernel, n <= 16
+template <class T>
+hipError_t launch_gp_rowlane(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                             int *info, hipStream_t stream);
 template <class T>
 bool rowlane_family_supports(int n);
 

@@ -214,10 +214,20 @@ constexpr int rowlane_occupancy(size_t elem, int np, bool full)
 // upper entries by the mirrored lower ones through a padded LDS tile of its wave: 2 LDS accesses per element against an
 // uncoalesced second address pattern that cost 40 % at n = 16) and a pivot that is not positive marks the matrix as not
 // positive definite (info = that column, as the Cholesky factorisation would).
-template <class T, int NP, bool FULL, bool SPD = false>
+// GP = the fused Gaussian-process scalars for n <= 16 (SPD mode on M = B + diag c): lane i ends up with row i of M^-1, so
+// a^T M^-1 d = sum_i a_i (sum_c X[i][c] d_c) is 16 DPP-broadcast FMAs and one sum over the lanes of the matrix; nothing
+// but ONE scalar per item is written.
+template <class T>
+struct RowlaneGp {
+    const T *a, *c, *d, *e;  // d == nullptr: variance, out = e - a^T M^-1 a
+    T *out;
+};
+
+template <class T, int NP, bool FULL, bool SPD = false, bool GP = false>
 __global__ __launch_bounds__(ROWLANE_THREADS, rowlane_occupancy(sizeof(T), NP, FULL)) void matinv_gj_rowlane(BatchRef<const T> Ain, BatchRef<T> Xout, int *info,
-                                                                     int n_rt, unsigned batch)
+                                                                     int n_rt, unsigned batch, RowlaneGp<T> gp)
 {
+    static_assert(!GP || SPD, "the fused pipeline runs the SPD elimination");
     constexpr int GPW = 64 / NP;  // matrices per wavefront
     const int n = FULL ? NP : n_rt;
     const int lane = threadIdx.x & 63;
@@ -234,10 +244,18 @@ __global__ __launch_bounds__(ROWLANE_THREADS, rowlane_occupancy(sizeof(T), NP, F
     // before the current ones are eliminated, so their HBM latency hides behind ~600 VALU instructions instead of being
     // exposed once per iteration (the kernel was measured 79 % waiting on memory without it).
     T nxt[NP];
+    T nxt_a = 0, nxt_c = 0, nxt_d = 0;
     auto load = [&](unsigned w) {
         const unsigned mat = w * GPW + g;
         const bool valid = mat < batch;
         const T *A = Ain.at(valid ? mat : batch - 1);
+        if (GP) {
+            const bool in = valid && row_in;
+            const size_t off = (size_t)(valid ? mat : 0) * n + (row_in ? i : 0);
+            nxt_a = in ? gp.a[off] : (T)0;
+            nxt_c = in ? gp.c[off] : (T)0;
+            nxt_d = in ? (gp.d ? gp.d[off] : nxt_a) : (T)0;
+        }
 #pragma unroll
         for (int c = 0; c < NP; ++c)
             nxt[c] = (valid && row_in && (FULL || c < n)) ? A[c * n + i] : ((i == c) ? (T)1 : (T)0);
@@ -247,11 +265,16 @@ __global__ __launch_bounds__(ROWLANE_THREADS, rowlane_occupancy(sizeof(T), NP, F
     for (unsigned w = wave0; w < n_waves; w += wave_stride) {
         const unsigned mat = w * GPW + g;
         const bool valid = mat < batch;
-        T *X = Xout.at(valid ? mat : batch - 1);
+        T *X = GP ? nullptr : Xout.at(valid ? mat : batch - 1);
 
         T a[NP];
 #pragma unroll
         for (int c = 0; c < NP; ++c) a[c] = nxt[c];
+        const T va = nxt_a, vd = nxt_d;
+        if (GP) {  // addDiagonal (gauss_bench.cu:38-43)
+#pragma unroll
+            for (int c = 0; c < NP; ++c) a[c] += (i == c) ? nxt_c : (T)0;
+        }
         if (w + wave_stride < n_waves) load(w + wave_stride);
         if (SPD) {  // upper triangle <- mirror of the lower one (whatever the caller left there is never used)
 #pragma unroll
@@ -323,7 +346,15 @@ __global__ __launch_bounds__(ROWLANE_THREADS, rowlane_occupancy(sizeof(T), NP, F
 
         // 3. store; undo the row swaps as a column permutation of the addresses
         const bool fail = bad != 0;
-        if (!any_swap) {
+        if (GP) {
+            T t = 0;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) t = fma(a[c], bcast_lane<NP>(vd, c), t);  // (M^-1 d)_i
+            T sres = va * t;
+#pragma unroll
+            for (int off = 1; off < NP; off <<= 1) sres += __shfl_xor(sres, off);  // sum over the lanes of the matrix
+            if (valid && i == 0) gp.out[mat] = fail ? nan_of<T>() : (gp.d ? sres : gp.e[mat] - sres);
+        } else if (!any_swap) {
 #pragma unroll
             for (int c = 0; c < NP; ++c)
                 if (valid && row_in && (FULL || c < n)) X[c * n + i] = fail ? nan_of<T>() : a[c];
@@ -346,8 +377,9 @@ bool rowlane_family_supports(int n) { return n >= 1 && n <= 16; }
 template bool rowlane_family_supports<double>(int);
 template bool rowlane_family_supports<float>(int);
 
-template <class T, int NP, bool FULL, bool SPD>
-static hipError_t launch_one(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+template <class T, int NP, bool FULL, bool SPD, bool GP = false>
+static hipError_t launch_one(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
+                             RowlaneGp<T> gp = RowlaneGp<T>())
 {
     const unsigned gpw = 64 / NP;
     const size_t waves = (batch + gpw - 1) / gpw;
@@ -360,8 +392,8 @@ static hipError_t launch_one(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
     }();
     const unsigned resident = 256u * (per_cu ? per_cu : (unsigned)rowlane_occupancy(sizeof(T), NP, FULL));
     const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
-    hipLaunchKernelGGL((matinv_gj_rowlane<T, NP, FULL, SPD>), dim3(grid), dim3(ROWLANE_THREADS), 0, stream, A, X, info, n,
-                       (unsigned)batch);
+    hipLaunchKernelGGL((matinv_gj_rowlane<T, NP, FULL, SPD, GP>), dim3(grid), dim3(ROWLANE_THREADS), 0, stream, A, X, info, n,
+                       (unsigned)batch, gp);
     return hipGetLastError();
 }
 
@@ -389,6 +421,25 @@ template hipError_t launch_gj_rowlane<double>(int, BatchRef<const double>, Batch
 template hipError_t launch_gj_rowlane<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
 template hipError_t launch_spd_rowlane<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
 template hipError_t launch_spd_rowlane<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
+
+template <class T>
+hipError_t launch_gp_rowlane(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                             int *info, hipStream_t stream)
+{
+    if (!rowlane_family_supports<T>(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    BatchRef<const T> A{Bs, (size_t)n * n, nullptr};
+    BatchRef<T> X{nullptr, 0, nullptr};
+    const RowlaneGp<T> gp{As, Cs, Ds, Es, out};
+    if (n == 16) return launch_one<T, 16, true, true, true>(n, A, X, batch, info, stream, gp);
+    if (n == 8) return launch_one<T, 8, true, true, true>(n, A, X, batch, info, stream, gp);
+    if (n < 8) return launch_one<T, 8, false, true, true>(n, A, X, batch, info, stream, gp);
+    return launch_one<T, 16, false, true, true>(n, A, X, batch, info, stream, gp);
+}
+template hipError_t launch_gp_rowlane<double>(int, const double *, const double *, const double *, const double *,
+                                              const double *, double *, size_t, int *, hipStream_t);
+template hipError_t launch_gp_rowlane<float>(int, const float *, const float *, const float *, const float *, const float *,
+                                             float *, size_t, int *, hipStream_t);
 
 const char *name_spd_rowlane(bool f64, int n)
 {
