@@ -408,7 +408,10 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             return MATINV_OK;
         }
     }
-    if (!lds_family_supports<T>(n)) {
+    // measured: the LDS kernel wins while two workgroups fit a CU (f32 up to n = 137: 4.7e6 vs 3.6e6 items/s at 130) and, in
+    // f64, over its whole range (2.0e6 vs 1.75e6 at 130); with one f32 workgroup per CU the blocked path wins (3.1e6 vs 1.6e6
+    // at 160)
+    if (!lds_family_supports<T>(n) || (sizeof(T) == 4 && n > 137)) {
         if (!global_family_supports<T>(n)) return fail(MATINV_ERR_UNSUPPORTED, "pipeline: n=%d exceeds the limit 1024", n);
         static const bool use_blocked = []() {
             const char *s = getenv("MATINV_GP_BLOCKED");  // A/B switch for profiling; default on
@@ -422,12 +425,14 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             if (eb != hipSuccess) return fail_hip(eb, "kernel launch");
             return MATINV_OK;
         }
-        hipError_t eg = launch_gp_global<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
-                                            static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
-                                            static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,
-                                            static_cast<hipStream_t>(stream));
-        if (eg != hipSuccess) return fail_hip(eg, "kernel launch");
-        return MATINV_OK;
+        if (!lds_family_supports<T>(n)) {
+            hipError_t eg = launch_gp_global<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
+                                                static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
+                                                static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,
+                                                static_cast<hipStream_t>(stream));
+            if (eg != hipSuccess) return fail_hip(eg, "kernel launch");
+            return MATINV_OK;
+        }
     }
     hipError_t e = launch_gp_lds<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
                                     variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
