@@ -24,11 +24,12 @@ __device__ __forceinline__ void gp_tile_body(const T *As, const T *Bs, const T *
     constexpr int NX = NT + 1;  // tile rows/cols of the bordered matrix; R = NT is the border
     constexpr int R = NT;
     constexpr int NKB = 4 * NT;
-    const int n = FULL ? N : n_rt;
     const bool variance = (Ds == nullptr);
     const int l = threadIdx.x;
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
+        int n = FULL ? N : n_rt;  // run-time n opaque once per matrix, predicates on the edge tiles only: see gj_tile_body
+        if (!FULL) asm volatile("" : "+s"(n));
         const T *B = Bs + (size_t)mat * n * n;
         const T *va = As + (size_t)mat * n;
         const T *vw = variance ? va : Ds + (size_t)mat * n;
@@ -45,7 +46,7 @@ __device__ __forceinline__ void gp_tile_body(const T *As, const T *Bs, const T *
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
-                    const bool in = FULL || (row < n && col < n);
+                    const bool in = FULL || ti < NT - 1 || (row < n && col < n);  // tj <= ti: only the last tile row reaches beyond n
                     const int hi = row > col ? row : col, lo = row > col ? col : row;
                     // only the lower triangle of B is read (mirror position inside the diagonal tiles)
                     T v = in ? B[(unsigned)(lo * n + hi)] : ((row == col) ? (T)1 : (T)0);
@@ -56,7 +57,7 @@ __device__ __forceinline__ void gp_tile_body(const T *As, const T *Bs, const T *
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) {
             const int col = 16 * tj + c;
-            const bool in = FULL || col < n;
+            const bool in = FULL || tj < NT - 1 || col < n;
             const T u = in ? va[col] : (T)0, w = in ? vw[col] : (T)0;
             acc[R][tj][0] = (q == 0) ? u : (q == 1) ? w : (T)0;  // border rows trow(0,0) (a) and trow(0,1) (d); the others are zero
             acc[R][tj][1] = (T)0, acc[R][tj][2] = (T)0, acc[R][tj][3] = (T)0;

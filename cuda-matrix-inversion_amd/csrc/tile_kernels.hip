@@ -334,12 +334,13 @@ __device__ __forceinline__ void spd_tile_body(BatchRef<const T> Ain, BatchRef<T>
     constexpr int N = 16 * NT;
     constexpr int NKB = 4 * NT;
     constexpr int TSTRIDE = 17;  // padded row stride of the 16x16 transpose buffer (conflict-free reads)
-    const int n = FULL ? N : n_rt;
     const int l = threadIdx.x;
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
         const T *A = Ain.at_uniform(mat);
         T *X = Xout.at_uniform(mat);
+        int n = FULL ? N : n_rt;  // run-time n opaque once per matrix, predicates on the edge tiles only: see gj_tile_body
+        if (!FULL) asm volatile("" : "+s"(n));
         int q = l >> 4, c = l & 15;
         const unsigned lane_off = (unsigned)((l >> 4) * n + (l & 15));
         asm volatile("" : "+v"(q), "+v"(c));  // see matinv_gj_tile_f64
@@ -361,11 +362,11 @@ __device__ __forceinline__ void spd_tile_body(BatchRef<const T> Ain, BatchRef<T>
                         // memory element (r_mem, c_mem) of column-major A sits at c_mem*n + r_mem; W[row][col] =
                         // mem[row*n + col] = A[col][row]; its mirror mem[col*n + row]. Lower triangle of A
                         // (r_mem >= c_mem) <=> mem index (small*n + big).
-                        v = (FULL || (row < n && col < n)) ? A[(unsigned)(lo * n + hi)] : ((row == col) ? (T)1 : (T)0);
+                        v = (FULL || ti < NT - 1 || (row < n && col < n)) ? A[(unsigned)(lo * n + hi)] : ((row == col) ? (T)1 : (T)0);
                     } else {
                         // ti > tj: row > col: W[row][col] = mem[row*n + col] = A[col][row] is in A's UPPER triangle;
                         // take its mirror A[row][col] = mem[col*n + row] instead
-                        v = (FULL || (row < n && col < n)) ? A[(unsigned)(col * n + row)] : (T)0;
+                        v = (FULL || ti < NT - 1 || (row < n && col < n)) ? A[(unsigned)(col * n + row)] : (T)0;  // tj < ti <= NT-1
                     }
                     acc[ti][tj][r] = v;
                 }
@@ -461,7 +462,7 @@ __device__ __forceinline__ void spd_tile_body(BatchRef<const T> Ain, BatchRef<T>
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
-                        if (FULL || (row < n && col < n)) X[(unsigned)(row * n + col)] = -acc[ti][tj][r];
+                        if (FULL || ti < NT - 1 || (row < n && col < n)) X[(unsigned)(row * n + col)] = -acc[ti][tj][r];
                     }
                     if (tj < ti) {
                         wave_lds_sync();
@@ -473,7 +474,7 @@ __device__ __forceinline__ void spd_tile_body(BatchRef<const T> Ain, BatchRef<T>
                             // element (row 16tj + 4r + q, col 16ti + c) of the result = tile(ti,tj)[c][4r + q]
                             const int row = 16 * tj + G::trow(r, q), col = 16 * ti + c;
                             const T v = panel[c * TSTRIDE + G::trow(r, q)];
-                            if (FULL || (row < n && col < n)) X[(unsigned)(row * n + col)] = v;
+                            if (FULL || ti < NT - 1 || (row < n && col < n)) X[(unsigned)(row * n + col)] = v;
                         }
                     }
                 }
