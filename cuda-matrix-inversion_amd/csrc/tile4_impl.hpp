@@ -1,0 +1,413 @@
+// tile4_impl.hpp (instantiated by tile4_kernels.hip for f64 and tile4_f32_kernels.hip for f32 -- two translation units so
+// that the two halves compile in parallel) -- kernel family "TILE" for 64 < n <= 128: SEVERAL wavefronts per matrix (1, 2 or 4: t4_waves() below; the
+// description is for four).
+//
+// Same blocked Gauss-Jordan on 16x16 fp64 MFMA accumulator tiles as tile_kernels.hip (read that header first), but a
+// 128 x 128 matrix is 64 tiles = 512 VGPRs per lane -- more than one wavefront may hold. A 256-thread workgroup owns a
+// matrix; wavefront w holds the tile COLUMNS w, w+4 (all NT tile rows of them, <= 16 tiles = 128 VGPRs). That split
+// keeps the two operands of the rank-4 update cheap:
+//   * B operand = pivot rows of the wave's own columns = its own accumulator registers, no exchange at all;
+//   * A operand = -W[:,K] D^-1 is needed by every wave: the wave that owns tile column kb/4 stages the 4 pivot columns
+//     in LDS (4 KB), then all four waves solve the 4x4 pivot block redundantly and form the same Aop (no second
+//     exchange, and the acceptance flag comes out identical in every wave).
+// Look-ahead: every wave first updates the local tile column that (for the next owner) holds the next pivot columns, the
+// next owner stages them into the OTHER half of a double-buffered LDS panel, one workgroup barrier, then the remaining
+// MFMAs run pinned between the stages of the next panel's solve. One barrier per block step.
+// Rejected matrices (a multiplier above TAU) go to the same device work list and are redone by the pivoted LDS kernel,
+// which handles every n this family serves.
+//
+// Replaces, for 64 < n <= 128, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95.
+#pragma once
+#include <cstdio>
+
+#include "tile_common.hpp"
+
+namespace matinv {
+
+
+// NT = tiles per dimension, T4_WAVES = wavefronts per matrix, NC = tile columns per wave = ceil(NT / T4_WAVES).
+// (Measured and not used: NT = 4 with 2 waves per 64 x 64 matrix, 142 VGPRs, 3 waves per SIMD: 4.7e7 inv/s against 6.1e7
+// for the one-wave kernel of tile_kernels.hip -- the redundant panel solve and the barriers cost more than the occupancy buys.)
+// SPD = the Cholesky entry point for 64 < n <= 128: the same sweep, but only the LOWER triangle of A is read (the upper
+// tiles are mirrored while loading, as the Cholesky contract demands -- include/matinv.h), the natural pivots are accepted
+// when they are all POSITIVE (leading principal minors of a symmetric matrix: positive definite; no multiplier test, the
+// sweep is stable on SPD input), and rejected matrices go to the LDS Cholesky, which reports the failing column.
+// GP = the fused Gaussian-process scalars for 64 < n <= 128 (SPD mode on M = B + diag c): the diagonal is added while
+// loading, and instead of storing M^-1 every wave folds its tile columns into a^T M^-1 d straight from the accumulator
+// registers (wave reduction, four partial sums through LDS): n^2 elements read, ONE scalar written per item.
+template <class T>
+struct GpArgs {
+    const T *a, *c, *d, *e;  // d == nullptr: variance, out = e - a^T M^-1 a
+    T *out;
+};
+
+template <class T, int NT, bool FULL, int T4_WAVES, bool SPD, bool GP = false>
+__device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
+                                              int *work_count, int *work_list, T *panel, GpArgs<T> gp = GpArgs<T>())
+{
+    static_assert(!GP || SPD, "the fused pipeline runs the SPD sweep");
+    typedef TileGeo<T> G;
+    typedef typename G::vec4 vec4;
+    constexpr int N = 16 * NT;
+    constexpr int NKB = 4 * NT;
+    constexpr int NC = (NT + T4_WAVES - 1) / T4_WAVES;
+    const int l = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;  // wave-uniform
+
+    for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
+        const T *A = Ain.at_uniform(mat);
+        T *X = Xout.at_uniform(mat);
+        // run-time n made opaque once per matrix: keeps LICM from hoisting the tile offsets and bounds predicates of the
+        // load and store loops out of the batch loop (370-510 VGPRs otherwise)
+        int n = FULL ? N : n_rt;
+        if (!FULL) asm volatile("" : "+s"(n));
+        int q = l >> 4, c = l & 15;
+        const unsigned lane_off = (unsigned)(G::trow(0, l >> 4) * n + (l & 15));
+        asm volatile("" : "+v"(q), "+v"(c));  // keep LICM from hoisting ~100 per-lane constants (see tile_kernels.hip)
+
+        // acc[ti][jl] = tile (ti, w + 4*jl); W = A^T as in the single-wave kernel
+        vec4 acc[NT][NC];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int jl = 0; jl < NC; ++jl) {
+                const int tj = w + T4_WAVES * jl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
+                    const unsigned uoff = (unsigned)((16 * ti + G::trow(r, 0)) * n + 16 * tj);
+                    // only the last tile row / a wave's last tile column can reach beyond n: interior tiles skip the test
+                    const bool edge = !FULL && (ti == NT - 1 || jl == NC - 1);
+                    const bool in = (tj < NT) && (!edge || (row < n && col < n));
+                    // W = A^T: W[row][col] = A[col][row] at col*... the batch is column-major, so uoff + lane_off addresses
+                    // A(col, row); its mirror A(row, col) sits at col * n + row
+                    const bool mirror = SPD && (col < row);  // A(col,row) with col < row is an UPPER element: read A(row,col)
+                    acc[ti][jl][r] = in ? (mirror ? A[(unsigned)(col * n + row)] : A[uoff + lane_off]) : ((row == col) ? (T)1 : (T)0);
+                    // addDiagonal (gauss_bench.cu:38-43): only the tile slot that can hold the diagonal tile of this tile row
+                    if (GP && jl == ti / T4_WAVES) {
+                        if (w == ti % T4_WAVES && row == col && (FULL || row < n)) acc[ti][jl][r] += gp.c[(size_t)mat * n + row];
+                    }
+                }
+            }
+        unsigned long long bad = 0;
+        T aop[NT], bop[NC];
+
+        // Look-ahead pipeline with ONE workgroup barrier per block step (the panel is double buffered in LDS):
+        //   every wave updates its local column jo_n first (for the next owner that is the column holding the next
+        //   pivot columns); the next owner stages them; barrier; the other local column is updated while every wave
+        //   solves the next panel (MFMAs pinned between the solve stages).
+        auto stage_panel = [&](int kb) {
+            const int tK = kb >> 2, rK = kb & 3, jo = tK / T4_WAVES;
+            T *buf = panel + (kb & 1) * (N * 4);
+            if (w == tK % T4_WAVES && G::blk(c) == rK) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) buf[(16 * ti + G::trow(r, q)) * 4 + G::piv(c)] = acc[ti][jo][r];
+            }
+        };
+        stage_panel(0);
+        __syncthreads();
+        {
+            PanelSolve<NT, SPD, T> ps0;
+#pragma unroll
+            for (int s0 = 0; s0 < PanelSolve<NT, SPD, T>::NSTAGE; ++s0) ps0.stage(s0, panel, 0, q, c, aop, bad);
+        }
+
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int tK = kb >> 2, rK = kb & 3;
+            const int owner = tK % T4_WAVES, jo = tK / T4_WAVES;  // wave and local column holding the pivot columns
+            const bool panel_lane = G::blk(c) == rK;
+            const bool diag_lane = panel_lane && (G::piv(c) == q);
+            // B operand: pivot rows of the wave's own columns; I_4 on the pivot columns (owner only)
+#pragma unroll
+            for (int jl = 0; jl < NC; ++jl) bop[jl] = acc[tK][jl][rK];
+            if (w == owner) bop[jo] = panel_lane ? (diag_lane ? (T)1 : (T)0) : bop[jo];
+            // C operand: zero on the pivot columns (owner) and on the pivot rows (everyone)
+            // One asm block per tile row, EXEC narrowed to the owner's pivot-column lanes and the block skipped when that is
+            // empty (every other wave): written as a C++ select hipcc emits 64 v_cndmask per step in EVERY wave (146 of
+            // ~250 VALU instructions per step; fp64 VALU and MFMA do not overlap on gfx950, so they cost), and with a
+            // scalar branch it merges the two paths with 32 register copies and twice the registers.
+            {
+                const unsigned long long zmask = __ballot((w == owner) && panel_lane);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    unsigned long long save;
+                    if constexpr (sizeof(T) == 8)
+                        asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
+                                     "s_cbranch_execz 1f\n\t"
+                                     "v_mov_b64_e32 %0, 0\n\t"
+                                     "v_mov_b64_e32 %1, 0\n\t"
+                                     "v_mov_b64_e32 %2, 0\n\t"
+                                     "v_mov_b64_e32 %3, 0\n"
+                                     "1:\n\t"
+                                     "s_mov_b64 exec, %[save]"
+                                     : "+v"(acc[ti][jo][0]), "+v"(acc[ti][jo][1]), "+v"(acc[ti][jo][2]), "+v"(acc[ti][jo][3]),
+                                       [save] "=&s"(save)
+                                     : [mask] "s"(zmask)
+                                     : "scc");
+                    else
+                        asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
+                                     "s_cbranch_execz 1f\n\t"
+                                     "v_mov_b32_e32 %0, 0\n\t"
+                                     "v_mov_b32_e32 %1, 0\n\t"
+                                     "v_mov_b32_e32 %2, 0\n\t"
+                                     "v_mov_b32_e32 %3, 0\n"
+                                     "1:\n\t"
+                                     "s_mov_b64 exec, %[save]"
+                                     : "+v"(acc[ti][jo][0]), "+v"(acc[ti][jo][1]), "+v"(acc[ti][jo][2]), "+v"(acc[ti][jo][3]),
+                                       [save] "=&s"(save)
+                                     : [mask] "s"(zmask)
+                                     : "scc");
+                }
+            }
+#pragma unroll
+            for (int jl = 0; jl < NC; ++jl) acc[tK][jl][rK] = (T)0;
+
+            if (kb + 1 < NKB) {
+                const int jn = ((kb + 1) >> 2) / T4_WAVES;  // local column updated first
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+                    acc[ti][jn] = G::mfma(aop[ti], bop[jn], acc[ti][jn]);
+                stage_panel(kb + 1);
+#ifndef TILE_DBG_NO_BARRIER
+                __syncthreads();
+#endif
+                const T *pnext = panel + ((kb + 1) & 1) * (N * 4);
+                constexpr int NS = PanelSolve<NT, SPD, T>::NSTAGE;
+                constexpr int NB = NT * (NC - 1);
+                T aop_next[NT];
+                PanelSolve<NT, SPD, T> ps;
+                int count = 0, ev = 0;
+                auto run_events = [&](bool flush) {
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        const int thr = (NB * e) / NS;
+                        if (e == ev && (flush || thr <= count)) {
+                            __builtin_amdgcn_sched_barrier(0);
+#ifndef TILE_DBG_NO_PANEL
+                            ps.stage(e, pnext, kb + 1, q, c, aop_next, bad);
+#else
+                            if (e >= 6) aop_next[e - 6] = aop[e - 6] * (T)0.5 + pnext[(16 * (e - 6) + c) * 4];
+#endif
+                            __builtin_amdgcn_sched_barrier(0);
+                            ++ev;
+                        }
+                    }
+                };
+                run_events(false);
+#pragma unroll
+                for (int jl = 0; jl < NC; ++jl) {
+                    if (jl == jn) continue;
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti) {
+                        acc[ti][jl] = G::mfma(aop[ti], bop[jl], acc[ti][jl]);
+                        ++count;
+                        run_events(false);
+                    }
+                }
+                run_events(true);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) aop[ti] = aop_next[ti];
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int jl = 0; jl < NC; ++jl)
+                        acc[ti][jl] = G::mfma(aop[ti], bop[jl], acc[ti][jl]);
+            }
+        }
+        __syncthreads();  // both panel buffers are free again before the next matrix stages its first panel
+
+        if (GP) {
+            if (bad == 0) {
+                // s = sum over this lane's elements a[row] X[row][col] d[col] (X symmetric, so the W = A^T labelling is immaterial)
+                const T *va = gp.a + (size_t)mat * n;
+                const T *vd = gp.d ? gp.d + (size_t)mat * n : va;
+                T s = 0;
+#pragma unroll
+                for (int jl = 0; jl < NC; ++jl) {
+                    const int tj = w + T4_WAVES * jl, col = 16 * tj + c;
+                    T t = 0;
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * ti + G::trow(r, q);
+                            const T ar = (FULL || ti < NT - 1 || row < n) ? va[row] : (T)0;  // identity padding contributes nothing
+                            t = fma_t(ar, acc[ti][jl][r], t);
+                        }
+                    const T dc = (tj < NT && (FULL || col < n)) ? vd[col] : (T)0;
+                    s = fma_t(dc, t, s);
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+                if (l == 0) panel[w] = s;  // both panel buffers are free (barrier above)
+            }
+            __syncthreads();
+            if (bad == 0 && threadIdx.x == 0) {
+                T sum = 0;
+#pragma unroll
+                for (int i = 0; i < T4_WAVES; ++i) sum += panel[i];
+                gp.out[mat] = gp.d ? sum : gp.e[mat] - sum;
+            }
+            __syncthreads();  // the next matrix stages its first panel into the same buffer
+        }
+        if (GP && bad == 0) {
+            if (info && threadIdx.x == 0) info[mat] = 0;
+        } else if (bad == 0) {  // identical in all four waves (they evaluate the same D and the same Aop)
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int jl = 0; jl < NC; ++jl) {
+                    const int tj = w + T4_WAVES * jl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
+                        const unsigned uoff = (unsigned)((16 * ti + G::trow(r, 0)) * n + 16 * tj);
+                        const bool edge = !FULL && (ti == NT - 1 || jl == NC - 1);
+                        if ((tj < NT) && (!edge || (row < n && col < n))) X[uoff + lane_off] = acc[ti][jl][r];
+                    }
+                }
+            if (info && threadIdx.x == 0) info[mat] = 0;
+        } else if (threadIdx.x == 0) {
+            const int slot = atomicAdd(work_count, 1);
+            work_list[slot] = (int)mat;
+        }
+    }
+}
+
+// SPD = the Cholesky entry point for 64 < n <= 128 (see gj_tile4_body).
+template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
+__global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
+                                                                       int *info, int n_rt, unsigned batch,
+                                                                       int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) double panel[2 * 16 * NT * 4];  // double buffered [row][4 pivot columns]
+    gj_tile4_body<double, NT, FULL, T4_WAVES, SPD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
+}
+// fp32 (the reference's DataType; its benchmark sweep goes up to n = 128): 16 tiles x 4 VGPRs per wave
+template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
+__global__ __launch_bounds__(64 * T4_WAVES, (T4_WAVES <= 2 ? 2 : 3)) void matinv_gj_tile4_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
+                                                                       int n_rt, unsigned batch, int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) float panel[2 * 16 * NT * 4];
+    gj_tile4_body<float, NT, FULL, T4_WAVES, SPD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
+}
+
+// fused mean / variance, 64 < n <= 128 (run-time n only: one instantiation per NT and dtype)
+template <int NT, int W>
+__global__ __launch_bounds__(64 * W, 2) void matinv_gp_tile4_f64(const double *As, const double *Bs, const double *Cs, const double *Ds,
+                                                             const double *Es, double *out, int *info, int n_rt, unsigned batch,
+                                                             int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) double panel[2 * 16 * NT * 4];
+    BatchRef<const double> A{Bs, (size_t)n_rt * n_rt, nullptr};
+    BatchRef<double> X{nullptr, 0, nullptr};
+    gj_tile4_body<double, NT, false, W, true, true>(A, X, info, n_rt, batch, work_count, work_list, panel,
+                                                   GpArgs<double>{As, Cs, Ds, Es, out});
+}
+template <int NT, int W>
+__global__ __launch_bounds__(64 * W, (W <= 2 ? 2 : 3)) void matinv_gp_tile4_f32(const float *As, const float *Bs, const float *Cs, const float *Ds,
+                                                             const float *Es, float *out, int *info, int n_rt, unsigned batch,
+                                                             int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) float panel[2 * 16 * NT * 4];
+    BatchRef<const float> A{Bs, (size_t)n_rt * n_rt, nullptr};
+    BatchRef<float> X{nullptr, 0, nullptr};
+    gj_tile4_body<float, NT, false, W, true, true>(A, X, info, n_rt, batch, work_count, work_list, panel,
+                                                  GpArgs<float>{As, Cs, Ds, Es, out});
+}
+
+// Wavefronts per matrix, by measurement (inv/s, FULL Gauss-Jordan, 1 / 2 / 3 / 4 waves; "-" = does not fit or spills badly):
+//   f64  n=80: - / 2.20e7 / 2.03e7 / 1.73e7    n=96: - / 1.66e7 / 1.23e7 / 1.16e7    n=112: - / - / 7.9e6 / 9.7e6    n=128: 4
+//   f32  n=80: 5.09e7 / 4.17e7 / 3.01e7 / 2.96e7    n=96: 2.99e7 / 2.86e7 / 2.22e7 / 2.22e7
+//        n=112: - / 1.90e7 / 1.75e7 / 1.73e7        n=128: - / 1.40e7 / 1.11e7 / 1.45e7
+// Every wave repeats the panel solve, so the fewest waves whose tile columns still fit the register file win (f32 n=96 on one
+// wave spills in the SPD / pipeline variants -- 2.6e7 and 1.9e7 against 2.7e7 and 2.2e7 on four -- so it takes two).
+constexpr int t4_waves(bool f64, int nt) { return f64 ? (nt <= 6 ? 2 : 4) : (nt <= 5 ? 1 : (nt <= 7 ? 2 : 4)); }
+
+template <class T, bool SPD>
+static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    if (!tile4_supports(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int nt = (n + 15) / 16;
+    const unsigned grid = (unsigned)(batch < 256u * 3u * tile_grid_rounds() ? batch : 256u * 3u * tile_grid_rounds());
+    const unsigned b = (unsigned)batch;
+#define T4_LAUNCH(NT_)                                                                                                \
+    if constexpr (sizeof(T) == 8) {                                                                                   \
+        if (n == 16 * NT_)                                                                                            \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 1); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    } else {                                                                                                          \
+        if (n == 16 * NT_)                                                                                            \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, true, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 1); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    }
+    switch (nt) {
+    case 5: T4_LAUNCH(5) break;
+    case 6: T4_LAUNCH(6) break;
+    case 7: T4_LAUNCH(7) break;
+    default: T4_LAUNCH(8) break;
+    }
+#undef T4_LAUNCH
+    e = hipGetLastError();
+    if (e == hipSuccess)
+        e = SPD ? launch_chol_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream)
+                : launch_gj_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream);
+    hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+
+template <class T>
+hipError_t launch_gj_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    return launch_tile4<T, false>(n, A, X, batch, info, stream);
+}
+template <class T>
+hipError_t launch_spd_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    return launch_tile4<T, true>(n, A, X, batch, info, stream);
+}
+template <class T>
+hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                           int *info, hipStream_t stream)
+{
+    if (!tile4_supports(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int nt = (n + 15) / 16;
+    const unsigned occ = sizeof(T) == 8 ? 2u : 3u;
+    const unsigned grid = (unsigned)(batch < 256u * occ * tile_grid_rounds() ? batch : 256u * occ * tile_grid_rounds());
+    const unsigned b = (unsigned)batch;
+#define GP4_LAUNCH(NT_)                                                                                               \
+    if constexpr (sizeof(T) == 8)                                                                                     \
+        hipLaunchKernelGGL((matinv_gp_tile4_f64<NT_, t4_waves(true, NT_)>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((matinv_gp_tile4_f32<NT_, t4_waves(false, NT_)>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1);
+    switch (nt) {
+    case 5: GP4_LAUNCH(5) break;
+    case 6: GP4_LAUNCH(6) break;
+    case 7: GP4_LAUNCH(7) break;
+    default: GP4_LAUNCH(8) break;
+    }
+#undef GP4_LAUNCH
+    e = hipGetLastError();
+    if (e == hipSuccess) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
+    hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+}  // namespace matinv
