@@ -33,7 +33,7 @@ NATIVE_NAMES = [
     "matinv_inverse_batched", "matinv_inverse_batched_ex", "matinv_select_kernel", "matinv_kernel_name",
     "matinv_mean_batched", "matinv_variance_batched", "matinv_inverse_batched_host", "matinv_mean_batched_host",
     "matinv_variance_batched_host", "matinv_last_error",
-    "matinv_abi_version",
+    "matinv_abi_version", "matinv_release_cache",
 ]
 
 
@@ -82,6 +82,7 @@ def lib() -> ctypes.CDLL:
         f.argtypes = [ci, ci, vp, vp, vp, vp, vp, sz, vp]
     L.matinv_last_error.restype = ctypes.c_char_p
     L.matinv_abi_version.restype = ci
+    L.matinv_release_cache.restype = ci
     for suffix in ("", "_f32"):
         for name in REFERENCE_GPU_NAMES + REFERENCE_DEVICE_NAMES:
             f = getattr(L, name + suffix)

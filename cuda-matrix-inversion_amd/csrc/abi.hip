@@ -52,6 +52,26 @@ int check_device()
     return MATINV_OK;
 }
 
+// Staging buffers of the host-pointer entry points come from the device's default memory pool with its release threshold
+// raised once, so that the reference-style "allocate, copy, run, copy, free inside every call" (batched_invert.cu:120-176)
+// stops paying hipMalloc / hipFree (about 0.5 ms per call) after the first call; the pool hands the same blocks back.
+hipError_t staging_alloc(void **p, size_t bytes)
+{
+    static const bool pool_ready = []() {
+        int dev = 0;
+        hipMemPool_t pool;
+        unsigned long long keep = ~0ull;
+        return hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess &&
+               hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess;
+    }();
+    (void)pool_ready;
+    return hipMallocAsync(p, bytes, nullptr);
+}
+void staging_free(void *p)
+{
+    if (p) (void)hipFreeAsync(p, nullptr);
+}
+
 template <class T>
 int select_auto(int algo, int n)
 {
@@ -276,14 +296,14 @@ int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int
     int *dInfo = nullptr;
     hipError_t e;
     const bool log = detailed_logging() && log_prefix;
-    if ((e = hipMalloc(&dA, elems * sizeof(T))) != hipSuccess) return fail_hip(e, "hipMalloc(As)");
-    if ((e = hipMalloc(&dX, elems * sizeof(T))) != hipSuccess) {
-        (void)hipFree(dA);
+    if ((e = staging_alloc(reinterpret_cast<void **>(&dA), elems * sizeof(T))) != hipSuccess) return fail_hip(e, "hipMalloc(As)");
+    if ((e = staging_alloc(reinterpret_cast<void **>(&dX), elems * sizeof(T))) != hipSuccess) {
+        staging_free(dA);
         return fail_hip(e, "hipMalloc(aInvs)");
     }
-    if (info && (e = hipMalloc(&dInfo, batch * sizeof(int))) != hipSuccess) {
-        (void)hipFree(dA);
-        (void)hipFree(dX);
+    if (info && (e = staging_alloc(reinterpret_cast<void **>(&dInfo), batch * sizeof(int))) != hipSuccess) {
+        staging_free(dA);
+        staging_free(dX);
         return fail_hip(e, "hipMalloc(info)");
     }
     double t0 = now_ms();
@@ -298,9 +318,9 @@ int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int
     if (e == hipSuccess && rc == MATINV_OK && info)
         e = hipMemcpy(info, dInfo, batch * sizeof(int), hipMemcpyDeviceToHost);
     double t3 = now_ms();
-    (void)hipFree(dA);
-    (void)hipFree(dX);
-    if (dInfo) (void)hipFree(dInfo);
+    staging_free(dA);
+    staging_free(dX);
+    staging_free(dInfo);
     if (rc != MATINV_OK) return rc;
     if (e != hipSuccess) return fail_hip(e, "host<->device copy");
     if (log) {
@@ -459,10 +479,10 @@ int gp_host(int n, const void *hA, const void *hB, const void *hC, const void *h
     int *dInfo = nullptr;
     hipError_t e = hipSuccess;
     auto alloc = [&](T **p, size_t count) {
-        if (e == hipSuccess) e = hipMalloc(p, count * sizeof(T));
+        if (e == hipSuccess) e = staging_alloc(reinterpret_cast<void **>(p), count * sizeof(T));
     };
     alloc(&dA, vec), alloc(&dB, mat), alloc(&dC, vec), alloc(&dX, xlen), alloc(&dOut, batch);
-    if (e == hipSuccess && info) e = hipMalloc(&dInfo, batch * sizeof(int));
+    if (e == hipSuccess && info) e = staging_alloc(reinterpret_cast<void **>(&dInfo), batch * sizeof(int));
     const double t0 = now_ms();
     auto h2d = [&](T *d, const void *h, size_t count) {
         if (e == hipSuccess) e = hipMemcpy(d, h, count * sizeof(T), hipMemcpyHostToDevice);
@@ -478,8 +498,8 @@ int gp_host(int n, const void *hA, const void *hB, const void *hC, const void *h
     if (e == hipSuccess && rc == MATINV_OK) e = hipMemcpy(hOut, dOut, batch * sizeof(T), hipMemcpyDeviceToHost);
     if (e == hipSuccess && rc == MATINV_OK && info) e = hipMemcpy(info, dInfo, batch * sizeof(int), hipMemcpyDeviceToHost);
     const double t3 = now_ms();
-    (void)hipFree(dA), (void)hipFree(dB), (void)hipFree(dC), (void)hipFree(dX), (void)hipFree(dOut);
-    if (dInfo) (void)hipFree(dInfo);
+    staging_free(dA), staging_free(dB), staging_free(dC), staging_free(dX), staging_free(dOut);
+    staging_free(dInfo);
     if (rc != MATINV_OK) return rc;
     if (e != hipSuccess) return fail_hip(e, "pipeline host<->device");
     if (log) {
@@ -506,6 +526,20 @@ void die_on(int rc, const char *fn)
 extern "C" {
 
 int matinv_abi_version(void) { return 1; }
+
+int matinv_release_cache(void)
+{
+    int rc = check_device();
+    if (rc) return rc;
+    int dev = 0;
+    hipMemPool_t pool;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipDeviceGetDefaultMemPool(&pool, dev);
+    if (e == hipSuccess) e = hipMemPoolTrimTo(pool, 0);
+    if (e != hipSuccess) return fail_hip(e, "release cache");
+    return MATINV_OK;
+}
 const char *matinv_last_error(void) { return g_err; }
 
 int matinv_inverse_batched_ex(int algo, int dtype, int n, const void *dA, size_t strideA, void *dAinv,

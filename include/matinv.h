@@ -113,6 +113,12 @@ int matinv_variance_batched_host(int dtype, int n, const void *hAs, const void *
 const char *matinv_last_error(void);
 int matinv_abi_version(void);
 
+/* The host-pointer entry points (and the work lists of the kernels) take their device staging memory from the current
+ * device's default memory pool and leave it there between calls -- the reference's "allocate and free inside every call"
+ * (src/gauss/batched_invert.cu:120-176) without its cost. This hands everything that is not in use back to the driver.
+ * Returns MATINV_OK, or MATINV_ERR_HIP / MATINV_ERR_NO_DEVICE. Never needed for correctness. */
+int matinv_release_cache(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -471,6 +471,28 @@ def test_reference_host_pointer_family(name, dtype, n, batch):
     assert rel_err(out.astype(np.float64), want, n) < (1e-10 if dtype == np.float64 else 1e-4)
 
 
+def test_staging_cache_is_reused_and_can_be_released():
+    """Repeated host-pointer calls reuse the pooled staging buffers (same results), and matinv_release_cache() hands the
+    pool back to the driver without affecting later calls."""
+    L = pkg("_lib").lib()
+    n, batch = 48, 300
+    a = spd_batch(n, batch, seed=5)
+    want, _ = oracle.inverse_batched(a, n)
+    outs = []
+    for _ in range(3):
+        out = np.zeros_like(a)
+        api.inverse_gauss_batched_gpu(n, a, out, batch)
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    assert rel_err(outs[0], want, n) < 1e-10
+    free0 = torch.cuda.mem_get_info()[0]
+    assert L.matinv_release_cache() == 0
+    assert torch.cuda.mem_get_info()[0] >= free0
+    out = np.zeros_like(a)
+    api.inverse_gauss_batched_gpu(n, a, out, batch)
+    assert np.array_equal(out, outs[0])
+
+
 def _table(ptrs):
     arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
     return arr
