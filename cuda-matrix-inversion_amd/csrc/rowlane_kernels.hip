@@ -14,6 +14,7 @@
 //
 // Replaces, for small n, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95 (pivotRow :17-45,
 // normalizeRow :47-57, transform_matrix :59-82) with one launch that touches HBM once per element.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -441,20 +442,15 @@ template hipError_t launch_gp_rowlane<double>(int, const double *, const double 
 template hipError_t launch_gp_rowlane<float>(int, const float *, const float *, const float *, const float *, const float *,
                                              float *, size_t, int *, hipStream_t);
 
-const char *name_spd_rowlane(bool f64, int n)
+// as rocprofv3 prints the instantiations (default template arguments spelled out)
+static const char *rowlane_name(bool f64, int n, bool spd)
 {
-    if (n == 16) return f64 ? "matinv_gj_rowlane<double, 16, true, true>" : "matinv_gj_rowlane<float, 16, true, true>";
-    if (n == 8) return f64 ? "matinv_gj_rowlane<double, 8, true, true>" : "matinv_gj_rowlane<float, 8, true, true>";
-    if (n < 8) return f64 ? "matinv_gj_rowlane<double, 8, false, true>" : "matinv_gj_rowlane<float, 8, false, true>";
-    return f64 ? "matinv_gj_rowlane<double, 16, false, true>" : "matinv_gj_rowlane<float, 16, false, true>";
+    static thread_local char buf[80];
+    snprintf(buf, sizeof buf, "matinv_gj_rowlane<%s, %d, %s, %s, false>", f64 ? "double" : "float", n <= 8 ? 8 : 16,
+             (n == 8 || n == 16) ? "true" : "false", spd ? "true" : "false");
+    return buf;
 }
-
-const char *name_gj_rowlane(bool f64, int n)
-{
-    if (n == 16) return f64 ? "matinv_gj_rowlane<double, 16, true>" : "matinv_gj_rowlane<float, 16, true>";
-    if (n == 8) return f64 ? "matinv_gj_rowlane<double, 8, true>" : "matinv_gj_rowlane<float, 8, true>";
-    if (n < 8) return f64 ? "matinv_gj_rowlane<double, 8, false>" : "matinv_gj_rowlane<float, 8, false>";
-    return f64 ? "matinv_gj_rowlane<double, 16, false>" : "matinv_gj_rowlane<float, 16, false>";
-}
+const char *name_spd_rowlane(bool f64, int n) { return rowlane_name(f64, n, true); }
+const char *name_gj_rowlane(bool f64, int n) { return rowlane_name(f64, n, false); }
 
 }  // namespace matinv
