@@ -78,6 +78,10 @@ __device__ __forceinline__ void prep_operands(typename TileGeo<T>::vec4 (&acc)[N
 // (Tried, not kept: letting a matrix that has already failed the acceptance test skip the remaining block steps through
 // nested scalar branches after every fourth step -- no loop exit, accumulators dead on the rejected path. hipcc answers the
 // control flow with 256 VGPRs + 344 B of scratch in the headline kernel instead of 212 and none.)
+// (Tried and measured, not kept: pinning "B operand = copy of the pivot-row register, then zero it" as two asm moves per tile
+// column -- hipcc copies the whole 4-register tile instead, 768 v_mov per 64x64 matrix. The asm version issues 173 fewer
+// VALU instructions per matrix (2 653 -> 2 480, 200 VGPRs instead of 212) and is SLOWER, 1.62 vs 1.59 ms per 100 k x 64^2 and
+// -15 % at 48x48: the volatile blocks stop the scheduler from spreading the moves between the MFMAs.)
 // (Tried and measured, not kept: streaming half of the wave's NEXT matrix into LDS with global_load_lds_dwordx4 during
 // the elimination. The exposed time per matrix is load LATENCY, not bytes: 1.651 ms with, 1.645 ms without at 100 k x 64^2.)
 template <class T, int NT, bool FULL, bool LOOKAHEAD>
