@@ -80,8 +80,10 @@ __device__ __forceinline__ void prep_operands(typename TileGeo<T>::vec4 (&acc)[N
 // control flow with 256 VGPRs + 344 B of scratch in the headline kernel instead of 212 and none.)
 // (Tried and measured, not kept: pinning "B operand = copy of the pivot-row register, then zero it" as two asm moves per tile
 // column -- hipcc copies the whole 4-register tile instead, 768 v_mov per 64x64 matrix. The asm version issues 173 fewer
-// VALU instructions per matrix (2 653 -> 2 480, 200 VGPRs instead of 212) and is SLOWER, 1.62 vs 1.59 ms per 100 k x 64^2 and
-// -15 % at 48x48: the volatile blocks stop the scheduler from spreading the moves between the MFMAs.)
+// VALU instructions per matrix (2 653 -> 2 480, 200 VGPRs instead of 212) and, A/B on one box, is 1 % faster at 64x64
+// (1.556 vs 1.575 ms per 100 k), 2-6 % at 48x48. But hipcc inserts no hazard wait states after an asm block: a move inside it
+// followed directly by the MFMA that reads the register is a VALU-write -> MFMA-read hazard, and the same change in the
+// four-wave kernel did produce wrong results. Not worth 1 %.)
 // (Tried and measured, not kept: streaming half of the wave's NEXT matrix into LDS with global_load_lds_dwordx4 during
 // the elimination. The exposed time per matrix is load LATENCY, not bytes: 1.651 ms with, 1.645 ms without at 100 k x 64^2.)
 template <class T, int NT, bool FULL, bool LOOKAHEAD>
