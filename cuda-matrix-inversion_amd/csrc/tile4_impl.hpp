@@ -140,7 +140,8 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                                      "v_mov_b64_e32 %0, 0\n\t"
                                      "v_mov_b64_e32 %1, 0\n\t"
                                      "v_mov_b64_e32 %2, 0\n\t"
-                                     "v_mov_b64_e32 %3, 0\n"
+                                     "v_mov_b64_e32 %3, 0\n\t"
+                                     "s_nop 1\n"  // wait states for the MFMA that reads these registers: hipcc pads nothing inside asm
                                      "1:\n\t"
                                      "s_mov_b64 exec, %[save]"
                                      : "+v"(acc[ti][jo][0]), "+v"(acc[ti][jo][1]), "+v"(acc[ti][jo][2]), "+v"(acc[ti][jo][3]),
@@ -153,7 +154,8 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                                      "v_mov_b32_e32 %0, 0\n\t"
                                      "v_mov_b32_e32 %1, 0\n\t"
                                      "v_mov_b32_e32 %2, 0\n\t"
-                                     "v_mov_b32_e32 %3, 0\n"
+                                     "v_mov_b32_e32 %3, 0\n\t"
+                                     "s_nop 1\n"
                                      "1:\n\t"
                                      "s_mov_b64 exec, %[save]"
                                      : "+v"(acc[ti][jo][0]), "+v"(acc[ti][jo][1]), "+v"(acc[ti][jo][2]), "+v"(acc[ti][jo][3]),
