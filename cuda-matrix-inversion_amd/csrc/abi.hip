@@ -406,7 +406,7 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             const char *s = getenv("MATINV_GP_TILE");  // A/B switch for profiling; default on
             return !(s && *s == '0');
         }();
-        if (use_tile && gp_tile_supports(n)) {
+        if (use_tile && gp_tile_supports(sizeof(T) == 8, n)) {
             hipError_t e = launch_gp_tile<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
                                              static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
                                              static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,

@@ -150,8 +150,8 @@ const char *name_gj_tile(bool f64, int n);
 template <class T>
 hipError_t launch_gp_lds_worklist(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out,
                                   const int *work_count, const int *work_list, int *info, hipStream_t stream);
-// fused GP scalars on the MFMA tile layout, n <= 64, f64 and f32 (gp_tile_kernels.hip)
-bool gp_tile_supports(int n);
+// fused GP scalars on the MFMA tile layout, one wavefront per item: f64 n <= 80, f32 n <= 96 (gp_tile_kernels.hip)
+bool gp_tile_supports(bool f64, int n);
 template <class T>
 hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
                           int *info, hipStream_t stream);

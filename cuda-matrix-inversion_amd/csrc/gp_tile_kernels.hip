@@ -10,6 +10,8 @@
 // Tile columns left of the current pivot block are dead and skipped (no inverse is wanted), so the work is that of a
 // Cholesky factorisation with two right-hand sides; HBM traffic per item is the lower triangle of B plus three
 // vectors in, one scalar out. Not SPD (a pivot <= 0) -> device work list -> matinv_gp_lds (info reported there).
+#include <cstdio>
+
 #include "tile_common.hpp"
 
 namespace matinv {
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, co
 }
 
 template <int NT, bool FULL>
-__global__ __launch_bounds__(64, 3) void matinv_gp_tile_f32(const float *As, const float *Bs, const float *Cs,
+__global__ __launch_bounds__(64, NT >= 6 ? 2 : 3) void matinv_gp_tile_f32(const float *As, const float *Bs, const float *Cs,
                                                            const float *Ds, const float *Es, float *out, int *info,
                                                            int n_rt, unsigned batch, int *work_count, int *work_list)
 {
@@ -171,13 +173,14 @@ __global__ __launch_bounds__(64, 3) void matinv_gp_tile_f32(const float *As, con
     gp_tile_body<float, NT, FULL>(As, Bs, Cs, Ds, Es, out, info, n_rt, batch, work_count, work_list, panel);
 }
 
-bool gp_tile_supports(int n) { return n >= 1 && n <= 64; }
+// one wavefront holds the bordered lower triangle up to 6 x 6 tiles in fp64 (n <= 80) and 7 x 7 in fp32 (n <= 96)
+bool gp_tile_supports(bool f64, int n) { return n >= 1 && n <= (f64 ? 80 : 96); }
 
 template <class T>
 hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
                           int *info, hipStream_t stream)
 {
-    if (!gp_tile_supports(n)) return hipErrorInvalidValue;
+    if (!gp_tile_supports(sizeof(T) == 8, n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -199,13 +202,23 @@ hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T 
         else                                                                                                          \
             hipLaunchKernelGGL((matinv_gp_tile_f32<NT_, false>), dim3(grid), dim3(64), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
     }
+#define GP_LAUNCH32(NT_)                                                                                              \
+    if constexpr (sizeof(T) == 4) {                                                                                   \
+        if (n == 16 * NT_)                                                                                            \
+            hipLaunchKernelGGL((matinv_gp_tile_f32<NT_, true>), dim3(grid), dim3(64), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((matinv_gp_tile_f32<NT_, false>), dim3(grid), dim3(64), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
+    }
     switch (nt) {
     case 1: GP_LAUNCH(1) break;
     case 2: GP_LAUNCH(2) break;
     case 3: GP_LAUNCH(3) break;
-    default: GP_LAUNCH(4) break;
+    case 4: GP_LAUNCH(4) break;
+    case 5: GP_LAUNCH(5) break;
+    default: GP_LAUNCH32(6) break;
     }
 #undef GP_LAUNCH
+#undef GP_LAUNCH32
     e = hipGetLastError();
     if (e == hipSuccess) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
@@ -218,14 +231,9 @@ template hipError_t launch_gp_tile<float>(int, const float *, const float *, con
 
 const char *name_gp_tile(bool f64, int n)
 {
-    const bool full = (n % 16) == 0;
-    const int nt = (n + 15) / 16;
-    static const char *names[2][2][4] = {
-        {{"matinv_gp_tile_f32<1, false>", "matinv_gp_tile_f32<2, false>", "matinv_gp_tile_f32<3, false>", "matinv_gp_tile_f32<4, false>"},
-         {"matinv_gp_tile_f32<1, true>", "matinv_gp_tile_f32<2, true>", "matinv_gp_tile_f32<3, true>", "matinv_gp_tile_f32<4, true>"}},
-        {{"matinv_gp_tile_f64<1, false>", "matinv_gp_tile_f64<2, false>", "matinv_gp_tile_f64<3, false>", "matinv_gp_tile_f64<4, false>"},
-         {"matinv_gp_tile_f64<1, true>", "matinv_gp_tile_f64<2, true>", "matinv_gp_tile_f64<3, true>", "matinv_gp_tile_f64<4, true>"}}};
-    return names[f64 ? 1 : 0][full ? 1 : 0][(nt < 1 ? 1 : nt > 4 ? 4 : nt) - 1];
+    static thread_local char buf[48];
+    snprintf(buf, sizeof buf, "matinv_gp_tile_%s<%d, %s>", f64 ? "f64" : "f32", (n + 15) / 16, (n % 16) == 0 ? "true" : "false");
+    return buf;
 }
 
 }  // namespace matinv

@@ -31,6 +31,7 @@
 // tests/generate_inverse_matrices.m:12-18) never take the fallback.
 //
 // Replaces the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "tile_common.hpp"
@@ -495,7 +496,7 @@ __device__ __forceinline__ void spd_tile_body(BatchRef<const T> Ain, BatchRef<T>
 
 
 template <int NT, bool FULL>
-__global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
+__global__ __launch_bounds__(64, NT >= 5 ? 2 : (NT >= 4 ? 3 : 4)) void matinv_spd_tile_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
                                                                           int *info, int n_rt, unsigned batch,
                                                                           int *work_count, int *work_list)
 {
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(64, NT >= 4 ? 3 : 4) void matinv_spd_tile_f64(Batch
 }
 
 template <int NT, bool FULL>
-__global__ __launch_bounds__(64, 4) void matinv_spd_tile_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
+__global__ __launch_bounds__(64, NT >= 7 ? 2 : (NT >= 5 ? 3 : 4)) void matinv_spd_tile_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
                                                             int n_rt, unsigned batch, int *work_count, int *work_list)
 {
     __shared__ __attribute__((aligned(16))) float panel[(16 * NT * 4 > 16 * 17) ? 16 * NT * 4 : 16 * 17];
@@ -627,7 +628,7 @@ hipError_t launch_spd_tile<float>(int n, BatchRef<const float> A, BatchRef<float
                                   hipStream_t stream)
 {
     if (!spd_tile_supports<float>(n)) return hipErrorInvalidValue;
-    if (n > 64) return launch_spd_tile4<float>(n, A, X, batch, info, stream);
+    if (n > 96) return launch_spd_tile4<float>(n, A, X, batch, info, stream);  // one wavefront holds the lower triangle up to 6 x 6 tiles
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -646,7 +647,9 @@ hipError_t launch_spd_tile<float>(int n, BatchRef<const float> A, BatchRef<float
     case 1: SPD_LAUNCH_F32(1); break;
     case 2: SPD_LAUNCH_F32(2); break;
     case 3: SPD_LAUNCH_F32(3); break;
-    default: SPD_LAUNCH_F32(4); break;
+    case 4: SPD_LAUNCH_F32(4); break;
+    case 5: SPD_LAUNCH_F32(5); break;
+    default: SPD_LAUNCH_F32(6); break;
     }
 #undef SPD_LAUNCH_F32
     e = hipGetLastError();
@@ -660,7 +663,7 @@ hipError_t launch_spd_tile<double>(int n, BatchRef<const double> A, BatchRef<dou
                                    hipStream_t stream)
 {
     if (!spd_tile_supports<double>(n)) return hipErrorInvalidValue;
-    if (n > 64) return launch_spd_tile4<double>(n, A, X, batch, info, stream);
+    if (n > 96) return launch_spd_tile4<double>(n, A, X, batch, info, stream);  // one wavefront holds the lower triangle up to 6 x 6 tiles
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -679,7 +682,9 @@ hipError_t launch_spd_tile<double>(int n, BatchRef<const double> A, BatchRef<dou
     case 1: SPD_LAUNCH(1); break;
     case 2: SPD_LAUNCH(2); break;
     case 3: SPD_LAUNCH(3); break;
-    default: SPD_LAUNCH(4); break;
+    case 4: SPD_LAUNCH(4); break;
+    case 5: SPD_LAUNCH(5); break;
+    default: SPD_LAUNCH(6); break;
     }
 #undef SPD_LAUNCH
     e = hipGetLastError();
@@ -690,22 +695,10 @@ hipError_t launch_spd_tile<double>(int n, BatchRef<const double> A, BatchRef<dou
 
 const char *name_spd_tile(bool f64, int n)
 {
-    const bool full = (n % 16) == 0;
-    if (n > 64) return name_tile4(f64, true, n);
-    if (!f64) {
-        switch ((n + 15) / 16) {
-        case 1: return full ? "matinv_spd_tile_f32<1, true>" : "matinv_spd_tile_f32<1, false>";
-        case 2: return full ? "matinv_spd_tile_f32<2, true>" : "matinv_spd_tile_f32<2, false>";
-        case 3: return full ? "matinv_spd_tile_f32<3, true>" : "matinv_spd_tile_f32<3, false>";
-        default: return full ? "matinv_spd_tile_f32<4, true>" : "matinv_spd_tile_f32<4, false>";
-        }
-    }
-    switch ((n + 15) / 16) {
-    case 1: return full ? "matinv_spd_tile_f64<1, true>" : "matinv_spd_tile_f64<1, false>";
-    case 2: return full ? "matinv_spd_tile_f64<2, true>" : "matinv_spd_tile_f64<2, false>";
-    case 3: return full ? "matinv_spd_tile_f64<3, true>" : "matinv_spd_tile_f64<3, false>";
-    default: return full ? "matinv_spd_tile_f64<4, true>" : "matinv_spd_tile_f64<4, false>";
-    }
+    if (n > 96) return name_tile4(f64, true, n);
+    static thread_local char buf[48];
+    snprintf(buf, sizeof buf, "matinv_spd_tile_%s<%d, %s>", f64 ? "f64" : "f32", (n + 15) / 16, (n % 16) == 0 ? "true" : "false");
+    return buf;
 }
 
 const char *name_gj_tile(bool f64, int n)
