@@ -173,8 +173,9 @@ __global__ __launch_bounds__(64, NT >= 6 ? 2 : 3) void matinv_gp_tile_f32(const 
     gp_tile_body<float, NT, FULL>(As, Bs, Cs, Ds, Es, out, info, n_rt, batch, work_count, work_list, panel);
 }
 
-// one wavefront holds the bordered lower triangle up to 6 x 6 tiles in fp64 (n <= 80) and 7 x 7 in fp32 (n <= 96)
-bool gp_tile_supports(bool f64, int n) { return n >= 1 && n <= (f64 ? 80 : 96); }
+// one wavefront holds the bordered lower triangle of up to 7 x 7 tiles (n <= 96; in fp64 the last size spills 292 B per lane
+// and still beats the several-wavefront kernel: 2.0e7 vs 1.8e7 items/s at 96 x 96)
+bool gp_tile_supports(bool, int n) { return n >= 1 && n <= 96; }
 
 template <class T>
 hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
@@ -215,7 +216,7 @@ hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T 
     case 3: GP_LAUNCH(3) break;
     case 4: GP_LAUNCH(4) break;
     case 5: GP_LAUNCH(5) break;
-    default: GP_LAUNCH32(6) break;
+    default: GP_LAUNCH(6) break;
     }
 #undef GP_LAUNCH
 #undef GP_LAUNCH32

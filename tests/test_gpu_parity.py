@@ -566,7 +566,7 @@ def test_pipeline_fixtures(d, n, gold):
     assert np.abs(v - r["variances"]).mean() < 5e-5
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 7, 8, 9, 12, 16, 17, 33, 64, 65, 80, 100, 127, 128, 129])
+@pytest.mark.parametrize("n", [1, 2, 5, 7, 8, 9, 12, 16, 17, 33, 64, 65, 80, 81, 88, 96, 97, 100, 127, 128, 129])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_pipeline_synthetic(n, dtype):
     rng = np.random.default_rng(n)
@@ -583,7 +583,7 @@ def test_pipeline_synthetic(n, dtype):
     assert np.abs(m - wm).max() < tol and np.abs(v - wv).max() < tol
 
 
-@pytest.mark.parametrize("n", [8, 13, 32, 100])
+@pytest.mark.parametrize("n", [8, 13, 32, 72, 90, 100])
 def test_pipeline_not_spd_reports_info_and_nan(n):
     batch = 6
     rng = np.random.default_rng(5)
