@@ -2,9 +2,9 @@
 
 The reference only sketches this ("use multiple queues for different sizes: 32, 128, 512, 1024",
 /root/reference/README.md:41-44) and never built it; BASELINE.json configs[4] asks for it. Items (a, B, c, d[, e]) of
-arbitrary n are appended to the queue of the smallest bin that holds them; `flush()` turns every non-empty queue into ONE
-device-resident batch -- items smaller than their bin are padded with an identity block in B and zeros in the vectors,
-which leaves a^T (B + diag c)^-1 d unchanged -- and launches the fused pipeline kernel of that bin on the bin's own HIP
+arbitrary n are appended to the queue of the smallest bin that holds them; `flush()` turns every non-empty queue into
+device-resident batches -- one per padded size, see SizeBinnedQueue; padding is an identity block in B and zeros in the
+vectors, which leaves a^T (B + diag c)^-1 d unchanged -- and launches the fused pipeline kernel on the bin's own HIP
 stream, so the bins overlap on the device. Results come back in submission order.
 
 torch supplies device memory and streams; all arithmetic is libmatinv_hip.so (api.calcluateMean / calcluateVariance).
@@ -54,8 +54,16 @@ def pad_items(a, B, c, d, n: int, nb: int, count: int):
 
 
 class SizeBinnedQueue:
-    def __init__(self, bins: Sequence[int] = DEFAULT_BINS, device=None):
+    """`pad_to="tile"` (default): inside a bin, items are grouped by n rounded up to a multiple of 16 (never beyond the bin) and
+    each group is one launch at that size -- the kernels serve any n, so an n = 40 item in the 128 bin costs what a 48 x 48
+    item costs, not what a 128 x 128 one does. `pad_to="bin"`: the reference sketch's literal policy, everything padded to
+    the bin size, one launch per bin."""
+
+    def __init__(self, bins: Sequence[int] = DEFAULT_BINS, device=None, pad_to: str = "tile"):
         import torch
+        if pad_to not in ("tile", "bin"):
+            raise ValueError("pad_to must be 'tile' or 'bin'")
+        self.pad_to = pad_to
         self.bins = tuple(sorted(bins))
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._queues = {b: [] for b in self.bins}   # bin -> list of chunks (first ticket, count, n, a, B, c, d, e)
@@ -102,18 +110,24 @@ class SizeBinnedQueue:
             s = self._streams[b]
             s.wait_stream(cur)  # the items were produced on the caller's stream
             with torch.cuda.stream(s):
-                padded = [pad_items(a, B, c, d, n, b, cnt) for (_, cnt, n, a, B, c, d, _) in q]
-                A_, B_, C_, D_ = (torch.cat([p[k] for p in padded]).contiguous() for k in range(4))
-                nitems = sum(ch[1] for ch in q)
-                idx = torch.cat([torch.arange(t, t + cnt, device=self.device) for (t, cnt, *_rest) in q]) \
-                    if len(q) < 64 else torch.tensor([t + i for (t, cnt, *_rest) in q for i in range(cnt)], device=self.device)
-                out = api.calcluateMean(b, A_, B_, C_, D_, batchSize=nitems)
-                means.index_copy_(0, idx, out)
-                if want_var:
-                    E_ = torch.cat([(ch[7].reshape(-1) if ch[7] is not None
-                                     else torch.zeros(ch[1], dtype=dtype, device=self.device)) for ch in q])
-                    var = api.calcluateVariance(b, A_, B_, C_, E_, batchSize=nitems)
-                    variances.index_copy_(0, idx, var)
+                groups = {}
+                for ch in q:
+                    pn = b if self.pad_to == "bin" else min(b, -(-ch[2] // 16) * 16)
+                    groups.setdefault(pn, []).append(ch)
+                for pn in sorted(groups, reverse=True):
+                    g = groups[pn]
+                    padded = [pad_items(a, B, c, d, n, pn, cnt) for (_, cnt, n, a, B, c, d, _) in g]
+                    A_, B_, C_, D_ = (torch.cat([p[k] for p in padded]).contiguous() for k in range(4))
+                    nitems = sum(ch[1] for ch in g)
+                    idx = torch.cat([torch.arange(t, t + cnt, device=self.device) for (t, cnt, *_rest) in g]) \
+                        if len(g) < 64 else torch.tensor([t + i for (t, cnt, *_rest) in g for i in range(cnt)], device=self.device)
+                    out = api.calcluateMean(pn, A_, B_, C_, D_, batchSize=nitems)
+                    means.index_copy_(0, idx, out)
+                    if want_var:
+                        E_ = torch.cat([(ch[7].reshape(-1) if ch[7] is not None
+                                         else torch.zeros(ch[1], dtype=dtype, device=self.device)) for ch in g])
+                        var = api.calcluateVariance(pn, A_, B_, C_, E_, batchSize=nitems)
+                        variances.index_copy_(0, idx, var)
         for s in self._streams.values():
             cur.wait_stream(s)
         self._queues = {b: [] for b in self.bins}

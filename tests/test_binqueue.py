@@ -60,6 +60,28 @@ def test_mixed_size_stream_matches_oracle(dtype):
 
 
 @pytest.mark.gpu
+def test_padding_policies_agree():
+    """pad_to="tile" (groups by n rounded up to 16 inside a bin) and pad_to="bin" (the literal policy) give the same scalars."""
+    import torch
+    bq = pkg("binqueue")
+    rng = np.random.default_rng(9)
+    sizes = [5, 17, 40, 100, 128, 33, 130, 300, 16, 64]
+    qa, qb = bq.SizeBinnedQueue(pad_to="tile"), bq.SizeBinnedQueue(pad_to="bin")
+    want = []
+    for i, n in enumerate(sizes):
+        B = spd_batch(n, 1, seed=200 + i)
+        a, c, d = (rng.random(n) for _ in range(3))
+        want.append(oracle.mean_batched(a, B, c, d, n)[0])
+        t = [torch.from_numpy(x).cuda() for x in (a, B, c, d)]
+        qa.submit(*t)
+        qb.submit(*t)
+    ma, mb = qa.flush()[0].cpu().numpy(), qb.flush()[0].cpu().numpy()
+    assert np.abs(ma - np.array(want)).max() < 1e-10 and np.abs(mb - np.array(want)).max() < 1e-10
+    with pytest.raises(ValueError):
+        bq.SizeBinnedQueue(pad_to="none")
+
+
+@pytest.mark.gpu
 def test_submit_many_matches_single_submits():
     """Chunked submission (same-size items back to back) gives the same results, in ticket order, as item-by-item."""
     import torch
