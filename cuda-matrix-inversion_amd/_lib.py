@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MATINV_LIB", os.path.join(_HERE, "libmatinv_hip.so"))
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 F64, F32 = 0, 1
 ALGO_GAUSS_JORDAN, ALGO_CHOLESKY = 0, 1
-KERNEL_AUTO, KERNEL_LDS, KERNEL_ROWLANE, KERNEL_TILE, KERNEL_ROW, KERNEL_GLOBAL, KERNEL_BLOCKED = 0, 1, 2, 3, 4, 5, 6
+KERNEL_AUTO, KERNEL_LDS, KERNEL_ROWLANE, KERNEL_TILE, KERNEL_ROW, KERNEL_GLOBAL, KERNEL_BLOCKED, KERNEL_TILEP = 0, 1, 2, 3, 4, 5, 6, 7
 
 REFERENCE_GPU_NAMES = [
     "inverse_gauss_batched_gpu", "inverse_lu_cuda_batched_gpu", "inverse_cholesky_stride_batched_gpu",

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (ALGO_CHOLESKY, ALGO_GAUSS_JORDAN, F32, F64, KERNEL_AUTO, KERNEL_BLOCKED, KERNEL_GLOBAL, KERNEL_LDS,  # noqa: F401
-                   KERNEL_ROW, KERNEL_ROWLANE, KERNEL_TILE, MatinvError)
+                   KERNEL_ROW, KERNEL_ROWLANE, KERNEL_TILE, KERNEL_TILEP, MatinvError)
 
 
 def _np_dtype_code(dtype) -> int:

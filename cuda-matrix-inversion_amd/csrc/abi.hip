@@ -149,6 +149,11 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
             return fail(MATINV_ERR_UNSUPPORTED, "blocked family serves the full SPD inverse with n <= 1024 only (n=%d)", n);
         e = launch_chol_blocked<T>(n, A, X, batch, dInfo, stream);
         break;
+    case MATINV_KERNEL_TILEP:
+        if (algo != MATINV_ALGO_GAUSS_JORDAN || !tilep_supports(n))
+            return fail(MATINV_ERR_UNSUPPORTED, "pivoting tile family serves Gauss-Jordan with n <= 64 only (n=%d)", n);
+        e = launch_gj_tilep<T>(n, A, X, batch, dInfo, stream);
+        break;
     case MATINV_KERNEL_ROW:
         if (algo != MATINV_ALGO_GAUSS_JORDAN || !row_family_supports<T>(n))
             return fail(MATINV_ERR_UNSUPPORTED, "row family serves Gauss-Jordan with n <= 64 only (n=%d)", n);
@@ -576,6 +581,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     case MATINV_KERNEL_ROWLANE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_rowlane(f64, n) : name_gj_rowlane(f64, n);
     case MATINV_KERNEL_TILE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_tile(f64, n) : name_gj_tile(f64, n);
     case MATINV_KERNEL_ROW: return name_gj_row(f64, n);
+    case MATINV_KERNEL_TILEP: return name_gj_tilep(f64, n);
     case MATINV_KERNEL_GLOBAL: return algo == MATINV_ALGO_CHOLESKY ? name_chol_global(f64) : name_gj_global(f64);
     case MATINV_KERNEL_BLOCKED:
         if (algo == MATINV_ALGO_GAUSS_JORDAN) return f64 ? "matinv_bgj_update<double>" : "matinv_bgj_update<float>";

@@ -145,6 +145,16 @@ template <class T>
 bool spd_tile_supports(int n);
 const char *name_spd_tile(bool f64, int n);
 
+// TILEP family (tilep_kernels.hip): the MFMA tile Gauss-Jordan with true partial pivoting inside the kernel, n <= 64
+bool tilep_supports(int n);
+template <class T>
+hipError_t launch_gj_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <>
+hipError_t launch_gj_tilep<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
+template <>
+hipError_t launch_gj_tilep<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
+const char *name_gj_tilep(bool f64, int n);
+
 const char *name_gj_rowlane(bool f64, int n);
 const char *name_gj_tile(bool f64, int n);
 template <class T>

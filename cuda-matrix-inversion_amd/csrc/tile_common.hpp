@@ -28,6 +28,10 @@ struct TileGeo<double> {
     static __device__ __forceinline__ int trow(int r, int q) { return 4 * r + q; }
     static __device__ __forceinline__ int blk(int c) { return c >> 2; }
     static __device__ __forceinline__ int piv(int c) { return c & 3; }
+    // tile-local column of pivot t in block rK; register / lane group of the tile-local row s (inverse of trow)
+    static __device__ __forceinline__ int pcol(int rK, int t) { return 4 * rK + t; }
+    static __device__ __forceinline__ int slot_r(int s) { return (s >> 2) & 3; }
+    static __device__ __forceinline__ int slot_q(int s) { return s & 3; }
     static __device__ __forceinline__ vec4 mfma(double a, double b, vec4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 };
 template <>
@@ -37,6 +41,9 @@ struct TileGeo<float> {
     static __device__ __forceinline__ int trow(int r, int q) { return 4 * q + r; }
     static __device__ __forceinline__ int blk(int c) { return c & 3; }
     static __device__ __forceinline__ int piv(int c) { return c >> 2; }
+    static __device__ __forceinline__ int pcol(int rK, int t) { return 4 * t + rK; }
+    static __device__ __forceinline__ int slot_r(int s) { return s & 3; }
+    static __device__ __forceinline__ int slot_q(int s) { return (s >> 2) & 3; }
     static __device__ __forceinline__ vec4 mfma(float a, float b, vec4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
 

@@ -1,0 +1,409 @@
+// tilep_impl.hpp (instantiated by tilep_kernels.hip for f64 and tilep_f32_kernels.hip for f32) -- kernel family "TILEP":
+// the MFMA accumulator-tile Gauss-Jordan of tile_kernels.inc (read that header first) with TRUE PARTIAL PIVOTING inside
+// the kernel, for GENERAL matrices, n <= 64, one matrix per wavefront.
+//
+// What pivoting changes. tile_kernels.inc eliminates in natural order: the four pivot rows of block kb are the rows that
+// ONE accumulator register (tile row kb/4, register kb%4) holds across the four lane groups, which makes the B operand
+// of the rank-4 update free. With a pivot search the four pivot rows of a block are wherever the search finds them:
+//   * rows never move (IMPLICIT pivoting): every row keeps its register slot for the whole elimination and the row /
+//     column permutation that this leaves behind is folded into the store addresses (two byte tables in LDS);
+//   * the search runs on the LDS-staged n x 4 panel with ONE ROW PER LANE (n <= 64 rows, 64 lanes): per pivot column a
+//     wave-wide DPP max over the top 32 bits of |x| of the rows not used yet, ballot + s_ff1 for the lowest row attaining
+//     it (the oracle's tie rule up to 2^-20 relative), the pivot row's four panel values and its earlier multipliers come
+//     back as SCALARS (8 v_readlane per pivot -- against 128 per step in row_kernels.hip), and each lane eliminates its
+//     own row: after four steps lane i holds the LU multipliers L_i of its row, and
+//           -W[i,K] D^-1 = -L_i L_D^-1        (D = L_D U, the four pivot rows in pivot order)
+//     so the A operand is a 4-term dot product per row exactly as in the unpivoted kernel; the pivot lanes publish
+//     -U^-1[t,:] instead of their L so that the SAME dot product yields their row of D^-1 -- no per-row select;
+//   * the four pivot rows reach the B operand through a 2 KB LDS buffer: a wave-uniform switch on the pivot's register
+//     slot (tile row, register) lets the one lane group that holds it store the row and zero it in C. That switch is the
+//     only place where a run-time register index is needed, and it is why the block-step loop is unrolled over the tile
+//     column only (the register index of the pivot COLUMNS) and rolled over the four blocks inside it.
+// Cost per block step at n = 64: ~45 more VALU instructions than the verified-natural-order kernel and three LDS round
+// trips instead of one; no acceptance test, no work list except for singular input (no finite non-zero pivot candidate),
+// which goes to the ROW kernel for its exact info code.
+//
+// Replaces pivotRow / normalizeRow / transform_matrix of /root/reference/src/gauss/batched_invert.cu:17-82 for inputs that
+// need row exchanges (the reference swaps only on an exactly zero diagonal, :19-35; tests/square_5_*.mats are such inputs).
+#pragma once
+#include <cstdio>
+
+#include "tile_common.hpp"
+#include "wave_util.hpp"
+
+namespace matinv {
+
+template <class T>
+struct Vec4Of;
+template <>
+struct Vec4Of<double> {
+    typedef v4d type;
+};
+template <>
+struct Vec4Of<float> {
+    typedef v4f type;
+};
+
+// B-operand gather of ONE pivot row (slot s = 16 ti + tile-local row) into the LDS row at byte address `bb_addr` (+ lane
+// offset): only the lane group that holds the row is active; its registers are zeroed afterwards (C operand of the pivot
+// rows: they become D^-1 W[P,:], a pure product). The register that holds the row is known at RUN time only. Written in
+// C++ (a switch over the 4 NT slots whose cases modify acc) hipcc merges the cases with whole-tile copies: 2 565 v_mov_b64
+// in the 64 x 64 kernel, 256 VGPRs and scratch. So: one asm block per tile row, unconditional for the compiler, that
+// branches over itself unless the pivot lives in this tile row, narrows EXEC to the lane group and picks the register with
+// scalar compares -- a dozen SALU instructions per pivot around NT ds_write + NT v_mov.
+template <class T, int NT, int TI>
+__device__ __forceinline__ void gather_zero_tile_row(typename TileGeo<T>::vec4 (&acc)[NT][NT], unsigned addr, int pos,
+                                                    unsigned long long mask)
+{
+    unsigned long long save;
+    unsigned tmp;
+    // dummy tiles keep the operand list of the asm the same for every NT (columns beyond NT are never touched at run time:
+    // their code is there, but the tile they name is a throw-away)
+    typename TileGeo<T>::vec4 dummy = {};
+#define TP_A(TJ, R) "+v"(((TJ) < NT ? acc[TI][(TJ) < NT ? (TJ) : 0] : dummy)[R])
+#define TP_W64(J, R, OFF) "ds_write_b64 %[addr], %[a" #J #R "] offset:" #OFF "\n\t"
+#define TP_W32(J, R, OFF) "ds_write_b32 %[addr], %[a" #J #R "] offset:" #OFF "\n\t"
+#define TP_Z64(J, R) "v_mov_b64_e32 %[a" #J #R "], 0\n\t"
+#define TP_Z32(J, R) "v_mov_b32_e32 %[a" #J #R "], 0\n\t"
+#define TP_WZ64_1(R) TP_W64(0, R, 0) TP_Z64(0, R)
+#define TP_WZ64_2(R) TP_W64(0, R, 0) TP_W64(1, R, 128) TP_Z64(0, R) TP_Z64(1, R)
+#define TP_WZ64_3(R) TP_W64(0, R, 0) TP_W64(1, R, 128) TP_W64(2, R, 256) TP_Z64(0, R) TP_Z64(1, R) TP_Z64(2, R)
+#define TP_WZ64_4(R) TP_W64(0, R, 0) TP_W64(1, R, 128) TP_W64(2, R, 256) TP_W64(3, R, 384) TP_Z64(0, R) TP_Z64(1, R) TP_Z64(2, R) TP_Z64(3, R)
+#define TP_WZ32_1(R) TP_W32(0, R, 0) TP_Z32(0, R)
+#define TP_WZ32_2(R) TP_W32(0, R, 0) TP_W32(1, R, 64) TP_Z32(0, R) TP_Z32(1, R)
+#define TP_WZ32_3(R) TP_W32(0, R, 0) TP_W32(1, R, 64) TP_W32(2, R, 128) TP_Z32(0, R) TP_Z32(1, R) TP_Z32(2, R)
+#define TP_WZ32_4(R) TP_W32(0, R, 0) TP_W32(1, R, 64) TP_W32(2, R, 128) TP_W32(3, R, 192) TP_Z32(0, R) TP_Z32(1, R) TP_Z32(2, R) TP_Z32(3, R)
+#define TP_BODY(WZ)                                                                                                    \
+    "s_lshr_b32 %[tmp], %[pos], 2\n\t"                                                                                 \
+    "s_cmp_lg_u32 %[tmp], %[ti]\n\t"                                                                                   \
+    "s_cbranch_scc1 9f\n\t"                                                                                            \
+    "s_and_saveexec_b64 %[save], %[mask]\n\t"                                                                          \
+    "s_and_b32 %[tmp], %[pos], 3\n\t"                                                                                  \
+    "s_cmp_lg_u32 %[tmp], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 1f\n\t" WZ(0) "s_branch 8f\n"                                                                      \
+    "1:\n\t"                                                                                                           \
+    "s_cmp_lg_u32 %[tmp], 1\n\t"                                                                                       \
+    "s_cbranch_scc1 2f\n\t" WZ(1) "s_branch 8f\n"                                                                      \
+    "2:\n\t"                                                                                                           \
+    "s_cmp_lg_u32 %[tmp], 2\n\t"                                                                                       \
+    "s_cbranch_scc1 3f\n\t" WZ(2) "s_branch 8f\n"                                                                      \
+    "3:\n\t" WZ(3) "8:\n\t"                                                                                            \
+    "s_nop 1\n\t"                                                                                                      \
+    "s_mov_b64 exec, %[save]\n"                                                                                        \
+    "9:"
+#define TP_OPERANDS                                                                                                    \
+    [a00] TP_A(0, 0), [a01] TP_A(0, 1), [a02] TP_A(0, 2), [a03] TP_A(0, 3), [a10] TP_A(1, 0), [a11] TP_A(1, 1),        \
+        [a12] TP_A(1, 2), [a13] TP_A(1, 3), [a20] TP_A(2, 0), [a21] TP_A(2, 1), [a22] TP_A(2, 2), [a23] TP_A(2, 3),    \
+        [a30] TP_A(3, 0), [a31] TP_A(3, 1), [a32] TP_A(3, 2), [a33] TP_A(3, 3), [save] "=&s"(save), [tmp] "=&s"(tmp)
+#define TP_EMIT(WZ) asm volatile(TP_BODY(WZ) : TP_OPERANDS : [addr] "v"(addr), [pos] "s"(pos), [mask] "s"(mask), [ti] "n"(TI) : "scc", "memory")
+    static_assert(NT >= 1 && NT <= 4, "one wavefront holds at most 4 x 4 tiles");
+    if constexpr (sizeof(T) == 8) {
+        if constexpr (NT == 1) TP_EMIT(TP_WZ64_1);
+        else if constexpr (NT == 2) TP_EMIT(TP_WZ64_2);
+        else if constexpr (NT == 3) TP_EMIT(TP_WZ64_3);
+        else TP_EMIT(TP_WZ64_4);
+    } else {
+        if constexpr (NT == 1) TP_EMIT(TP_WZ32_1);
+        else if constexpr (NT == 2) TP_EMIT(TP_WZ32_2);
+        else if constexpr (NT == 3) TP_EMIT(TP_WZ32_3);
+        else TP_EMIT(TP_WZ32_4);
+    }
+#undef TP_EMIT
+#undef TP_OPERANDS
+#undef TP_BODY
+#undef TP_A
+}
+
+template <class T, int NT, bool FULL>
+__device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
+                                              int *work_count, int *work_list, T *lds, unsigned char *tab)
+{
+    typedef TileGeo<T> G;
+    typedef typename G::vec4 vec4;
+    constexpr int N = 16 * NT;
+    T *const panel = lds;        // [64][4]  the four pivot columns, one row per lane
+    T *const lmat = lds + 256;   // [64][4]  multipliers L_i (pivot lanes: -U^-1 rows)
+    T *const bbuf = lds + 512;   // [4][N]   the four pivot rows in B-operand order
+    unsigned char *const rowaddr = tab, *const coladdr = tab + 64;
+    const int l = threadIdx.x;
+    // LDS byte address of this lane's element of pivot row 0 in bbuf (ds_write in gather_zero_tile_row)
+    typedef __attribute__((address_space(3))) T *lds_ptr;
+    const unsigned bb_lane = (unsigned)(size_t)(lds_ptr)(bbuf + (l & 15));
+
+    for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
+        const T *A = Ain.at_uniform(mat);
+        T *X = Xout.at_uniform(mat);
+        int n = FULL ? N : n_rt;
+        if (!FULL) asm volatile("" : "+s"(n));  // see gj_tile_body: keeps LICM away from the tile offsets
+        int q = l >> 4, c = l & 15, lr = l;
+        const unsigned lane_off = (unsigned)(G::trow(0, l >> 4) * n + (l & 15));
+        asm volatile("" : "+v"(q), "+v"(c), "+v"(lr));
+
+        vec4 acc[NT][NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
+                    const unsigned uoff = (unsigned)((16 * ti + G::trow(r, 0)) * n + 16 * tj);
+                    const bool edge = !FULL && (ti == NT - 1 || tj == NT - 1);
+                    acc[ti][tj][r] = (!edge || (row < n && col < n)) ? A[uoff + lane_off] : ((row == col) ? (T)1 : (T)0);
+                }
+
+        bool used = lr >= N;  // rows that may still become pivots: false. Lanes beyond N hold no row.
+        int bad = 0;
+
+#pragma unroll
+        for (int tK = 0; tK < NT; ++tK) {
+#pragma nounroll
+            for (int rK = 0; rK < 4; ++rK) {
+                const bool panel_lane = G::blk(c) == rK;
+                // ---- A. the four pivot columns -> LDS, [row slot][4]
+                if (panel_lane) {
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) panel[(16 * ti + G::trow(r, q)) * 4 + G::piv(c)] = acc[ti][tK][r];
+                }
+                wave_lds_sync();
+                // ---- B. pivot search + elimination of the panel, lane = row slot
+                const vec4 wv = *reinterpret_cast<const vec4 *>(&panel[lr * 4]);
+                T w0 = wv[0], w1 = wv[1], w2 = wv[2], w3 = wv[3];
+                int pv = 0;  // lane t holds the row slot of pivot t
+                auto pick = [&](T wk, int t) -> int {
+                    const bool cand = !used;
+                    const unsigned key = cand ? magkey(wk) : 0u;
+                    const unsigned mx = wave_max_u32(key);
+                    if (key_bad(T(0), mx) && bad == 0) bad = 4 * (4 * tK + rK) + t + 1;
+                    const unsigned long long vote = __ballot(cand && key == mx);
+                    const int p = vote ? (int)__builtin_ctzll(vote) : 0;
+                    used = used || (lr == p);
+                    pv = (lr == t) ? p : pv;
+                    return p;
+                };
+                // step 0
+                const int p0 = pick(w0, 0);
+                const T u00 = lane_value(w0, p0), u01 = lane_value(w1, p0), u02 = lane_value(w2, p0), u03 = lane_value(w3, p0);
+                const T r0 = rcp_full(u00);
+                T L0 = (lr == p0) ? (T)1 : w0 * r0;
+                w1 = fma_t(-L0, u01, w1), w2 = fma_t(-L0, u02, w2), w3 = fma_t(-L0, u03, w3);
+                // step 1
+                const int p1 = pick(w1, 1);
+                const T d10 = lane_value(L0, p1);
+                const T u11 = lane_value(w1, p1), u12 = lane_value(w2, p1), u13 = lane_value(w3, p1);
+                const T r1 = rcp_full(u11);
+                T L1 = (lr == p1) ? (T)1 : w1 * r1;
+                w2 = fma_t(-L1, u12, w2), w3 = fma_t(-L1, u13, w3);
+                // step 2
+                const int p2 = pick(w2, 2);
+                const T d20 = lane_value(L0, p2), d21 = lane_value(L1, p2);
+                const T u22 = lane_value(w2, p2), u23 = lane_value(w3, p2);
+                const T r2 = rcp_full(u22);
+                T L2 = (lr == p2) ? (T)1 : w2 * r2;
+                w3 = fma_t(-L2, u23, w3);
+                // step 3
+                const int p3 = pick(w3, 3);
+                const T d30 = lane_value(L0, p3), d31 = lane_value(L1, p3), d32 = lane_value(L2, p3);
+                const T u33 = lane_value(w3, p3);
+                const T r3 = rcp_full(u33);
+                T L3 = (lr == p3) ? (T)1 : w3 * r3;
+                // U^-1 (upper triangular, wave-uniform); pivot lane t publishes -U^-1[t,:] in place of its L row
+                const T i23 = -(u23 * r3) * r2;
+                const T i12 = -(u12 * r2) * r1;
+                const T i13 = -fma_t(u12, i23, u13 * r3) * r1;
+                const T i01 = -(u01 * r1) * r0;
+                const T i02 = -fma_t(u01, i12, u02 * r2) * r0;
+                const T i03 = -fma_t(u01, i13, fma_t(u02, i23, u03 * r3)) * r0;
+                {
+                    vec4 lv;
+                    lv[0] = L0, lv[1] = L1, lv[2] = L2, lv[3] = L3;
+                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = lv;
+                }
+                wave_lds_sync();
+                if (lr == p0) {
+                    vec4 v;
+                    v[0] = -r0, v[1] = -i01, v[2] = -i02, v[3] = -i03;
+                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = v;
+                }
+                if (lr == p1) {
+                    vec4 v;
+                    v[0] = (T)0, v[1] = -r1, v[2] = -i12, v[3] = -i13;
+                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = v;
+                }
+                if (lr == p2) {
+                    vec4 v;
+                    v[0] = (T)0, v[1] = (T)0, v[2] = -r2, v[3] = -i23;
+                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = v;
+                }
+                if (lr == p3) {
+                    vec4 v;
+                    v[0] = (T)0, v[1] = (T)0, v[2] = (T)0, v[3] = -r3;
+                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = v;
+                }
+                // permutation tables: column slot j_t was eliminated with row slot p_t
+                if (lr < 4) {
+                    const int j = 16 * tK + G::pcol(rK, lr);
+                    coladdr[j] = (unsigned char)pv;
+                    rowaddr[pv] = (unsigned char)j;
+                }
+                // L_D y = e_q: column q of L_D^-1 (per lane group)
+                const T y0 = (q == 0) ? (T)1 : (T)0;
+                const T y1 = fma_t(-d10, y0, (q == 1) ? (T)1 : (T)0);
+                const T y2 = fma_t(-d21, y1, fma_t(-d20, y0, (q == 2) ? (T)1 : (T)0));
+                const T y3 = fma_t(-d32, y2, fma_t(-d31, y1, fma_t(-d30, y0, (q == 3) ? (T)1 : (T)0)));
+                wave_lds_sync();
+                // ---- C. A operand: aop[ti] = Aop[16 ti + c][q] = -(L_i . y)
+                T aop[NT], bop[NT];
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    const vec4 lv = *reinterpret_cast<const vec4 *>(&lmat[(16 * ti + c) * 4]);
+                    aop[ti] = -fma_t(lv[3], y3, fma_t(lv[2], y2, fma_t(lv[1], y1, lv[0] * y0)));
+                }
+                // ---- D. B operand: the four pivot rows through LDS (and zero them in C)
+#pragma nounroll
+                for (int t = 0; t < 4; ++t) {
+                    const int s = __builtin_amdgcn_readlane(pv, t);
+                    const int loc = s & 15;
+                    const int pos = 4 * (s >> 4) + G::slot_r(loc);  // wave-uniform: 4 * tile row + register
+                    const unsigned long long mask = __ballot(q == G::slot_q(loc));
+                    const unsigned addr = bb_lane + (unsigned)(t * N * (int)sizeof(T));
+                    gather_zero_tile_row<T, NT, 0>(acc, addr, pos, mask);
+                    if constexpr (NT > 1) gather_zero_tile_row<T, NT, 1>(acc, addr, pos, mask);
+                    if constexpr (NT > 2) gather_zero_tile_row<T, NT, 2>(acc, addr, pos, mask);
+                    if constexpr (NT > 3) gather_zero_tile_row<T, NT, 3>(acc, addr, pos, mask);
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) bop[tj] = bbuf[q * N + 16 * tj + c];
+                // pivot columns: I_4 in B, zero in C (the MFMA then leaves Aop there)
+                bop[tK] = panel_lane ? ((G::piv(c) == q) ? (T)1 : (T)0) : bop[tK];
+                {
+                    // EXEC narrowed to the pivot-column lanes (written as a C++ select hipcc branches and copies the
+                    // tile column: see tile4_impl.hpp)
+                    const unsigned long long zmask = __ballot(panel_lane);
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti) {
+                        unsigned long long save;
+                        if constexpr (sizeof(T) == 8)
+                            asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
+                                         "v_mov_b64_e32 %0, 0\n\t"
+                                         "v_mov_b64_e32 %1, 0\n\t"
+                                         "v_mov_b64_e32 %2, 0\n\t"
+                                         "v_mov_b64_e32 %3, 0\n\t"
+                                         "s_nop 1\n\t"
+                                         "s_mov_b64 exec, %[save]"
+                                         : "+v"(acc[ti][tK][0]), "+v"(acc[ti][tK][1]), "+v"(acc[ti][tK][2]), "+v"(acc[ti][tK][3]),
+                                           [save] "=&s"(save)
+                                         : [mask] "s"(zmask)
+                                         : "scc");
+                        else
+                            asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
+                                         "v_mov_b32_e32 %0, 0\n\t"
+                                         "v_mov_b32_e32 %1, 0\n\t"
+                                         "v_mov_b32_e32 %2, 0\n\t"
+                                         "v_mov_b32_e32 %3, 0\n\t"
+                                         "s_nop 1\n\t"
+                                         "s_mov_b64 exec, %[save]"
+                                         : "+v"(acc[ti][tK][0]), "+v"(acc[ti][tK][1]), "+v"(acc[ti][tK][2]), "+v"(acc[ti][tK][3]),
+                                           [save] "=&s"(save)
+                                         : [mask] "s"(zmask)
+                                         : "scc");
+                    }
+                }
+                // ---- E. rank-4 update of every tile
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
+                wave_lds_sync();
+            }
+        }
+
+        if (bad == 0) {
+            // F[i][j] = inverse[rowaddr[i]][coladdr[j]] (see the header): W = A^T is stored as W[a][b] at a*n + b
+            unsigned ca[NT];
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) ca[tj] = coladdr[16 * tj + c];
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned ra = rowaddr[16 * ti + G::trow(r, q)];
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) {
+                        if (FULL || (ra < (unsigned)n && ca[tj] < (unsigned)n)) X[ra * (unsigned)n + ca[tj]] = acc[ti][tj][r];
+                    }
+                }
+            if (info && l == 0) info[mat] = 0;
+        } else if (l == 0) {
+            const int slot = atomicAdd(work_count, 1);
+            work_list[slot] = (int)mat;
+        }
+        wave_lds_sync();
+    }
+}
+
+template <int NT, bool FULL>
+__global__ __launch_bounds__(64, 2) void matinv_gj_tilep_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
+                                                            unsigned batch, int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) double lds[512 + 4 * 16 * NT];
+    __shared__ unsigned char tab[128];
+    gj_tilep_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab);
+}
+
+template <int NT, bool FULL>
+__global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n_rt,
+                                                            unsigned batch, int *work_count, int *work_list)
+{
+    __shared__ __attribute__((aligned(16))) float lds[512 + 4 * 16 * NT];
+    __shared__ unsigned char tab[128];
+    gj_tilep_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab);
+}
+
+template <class T>
+static hipError_t launch_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    if (n < 1 || n > 64) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e != hipSuccess) {
+        (void)hipFreeAsync(ws, stream);
+        return e;
+    }
+    const int nt = (n + 15) / 16;
+    const unsigned cap = 256u * 8u * tile_grid_rounds();
+    const unsigned grid = (unsigned)(batch < cap ? batch : cap);
+    const unsigned b = (unsigned)batch;
+#define TP_LAUNCH(NT_)                                                                                                 \
+    if constexpr (sizeof(T) == 8) {                                                                                    \
+        if (n == 16 * NT_)                                                                                             \
+            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    } else {                                                                                                           \
+        if (n == 16 * NT_)                                                                                             \
+            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    }
+    switch (nt) {
+    case 1: TP_LAUNCH(1) break;
+    case 2: TP_LAUNCH(2) break;
+    case 3: TP_LAUNCH(3) break;
+    default: TP_LAUNCH(4) break;
+    }
+#undef TP_LAUNCH
+    e = hipGetLastError();
+    // singular input only: the ROW kernel reports the exact step and NaN-fills the output
+    if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, ws, ws + 1, info, stream);
+    hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+
+}  // namespace matinv

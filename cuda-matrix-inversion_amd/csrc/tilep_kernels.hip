@@ -1,0 +1,21 @@
+// tilep_kernels.hip -- fp64 instantiations of the pivoting MFMA tile kernels (tilep_impl.hpp) and the family's helpers.
+#include "tilep_impl.hpp"
+
+namespace matinv {
+
+bool tilep_supports(int n) { return n >= 1 && n <= 64; }
+
+template <>
+hipError_t launch_gj_tilep<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream)
+{
+    return launch_tilep<double>(n, A, X, batch, info, stream);
+}
+
+const char *name_gj_tilep(bool f64, int n)
+{
+    static thread_local char buf[48];
+    snprintf(buf, sizeof buf, "matinv_gj_tilep_%s<%d, %s>", f64 ? "f64" : "f32", (n + 15) / 16, (n % 16) == 0 ? "true" : "false");
+    return buf;
+}
+
+}  // namespace matinv
