@@ -39,7 +39,13 @@ WORKLOADS = {
     "gj32": (32, "gj", "batch x 32x32 fp64 Gauss-Jordan"),
     "gj8": (8, "gj", "batch x 8x8 fp64 Gauss-Jordan"),
     "gj128": (128, "gj", "batch x 128x128 fp64 Gauss-Jordan"),
+    # GENERAL input: A ~ U(0,1)^(n x n), not symmetric, not dominant (like the reference's tests/square_5_*.mats): every
+    # matrix needs row exchanges
+    "gj64g": (64, "gj", "batch x 64x64 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
+    "gj32g": (32, "gj", "batch x 32x32 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
+    "gj128g": (128, "gj", "batch x 128x128 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
 }
+GENERAL = {"gj64g", "gj32g", "gj128g"}
 
 
 def make_spd(n, batch, seed, device):
@@ -48,6 +54,11 @@ def make_spd(n, batch, seed, device):
     a = r + r.transpose(1, 2)
     a.diagonal(dim1=1, dim2=2).add_(float(n))
     return a.reshape(-1).contiguous()
+
+
+def make_general(n, batch, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return torch.rand((batch * n * n,), generator=g, dtype=torch.float64, device=device)
 
 
 def usable_cores():
@@ -207,7 +218,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="gj64", choices=sorted(WORKLOADS) + ["mixed"])
     ap.add_argument("--batch", type=int, default=100_000, help="matrices per GPU per step")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "lds", "rowlane", "tile"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "lds", "rowlane", "tile", "tilep", "row"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other single-GPU workloads")
     args = ap.parse_args()
@@ -244,10 +255,11 @@ def main():
     n, algo_name, desc = WORKLOADS[args.workload]
     algo = api.ALGO_GAUSS_JORDAN if algo_name == "gj" else api.ALGO_CHOLESKY
     kernel = {"auto": api.KERNEL_AUTO, "lds": api.KERNEL_LDS, "rowlane": api.KERNEL_ROWLANE,
-              "tile": api.KERNEL_TILE}[args.kernel]
+              "tile": api.KERNEL_TILE, "tilep": api.KERNEL_TILEP, "row": api.KERNEL_ROW}[args.kernel]
     batch = args.batch
 
-    a = make_spd(n, batch, 0x5EED + rank, device)
+    general = args.workload in GENERAL
+    a = (make_general if general else make_spd)(n, batch, 0x5EED + rank, device)
     x = torch.empty_like(a)
     info = torch.empty(batch, dtype=torch.int32, device=device)
 
@@ -295,7 +307,7 @@ def main():
     am = a.view(batch, n, n)[:8]
     xm = x.view(batch, n, n)[:8]
     resid = float((torch.bmm(am, xm) - torch.eye(n, dtype=a.dtype, device=device)).abs().max())
-    assert resid < 1e-11 * n, f"residual {resid}"
+    assert resid < (1e-9 if general else 1e-11) * n, f"residual {resid}"
 
     # what a plain device-to-device copy of the same bytes reaches on this box (SURVEY 8d asks for the fraction against
     # the measured copy bandwidth beside the nominal 8 TB/s); torch's copy kernel, same read+write byte count

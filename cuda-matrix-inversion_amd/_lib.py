@@ -33,7 +33,8 @@ NATIVE_NAMES = [
     "matinv_inverse_batched", "matinv_inverse_batched_ex", "matinv_select_kernel", "matinv_kernel_name",
     "matinv_mean_batched", "matinv_variance_batched", "matinv_inverse_batched_host", "matinv_mean_batched_host",
     "matinv_variance_batched_host", "matinv_last_error",
-    "matinv_abi_version", "matinv_release_cache",
+    "matinv_abi_version", "matinv_release_cache", "matinv_batched_malloc", "matinv_batched_free", "matinv_memcpy_2d",
+    "matinv_device_synchronize",
 ]
 
 

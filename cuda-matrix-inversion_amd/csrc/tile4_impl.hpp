@@ -339,7 +339,10 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {
+        (void)hipFreeAsync(ws, stream);
+        return e;
+    }
     const int nt = (n + 15) / 16;
     const unsigned grid = (unsigned)(batch < 256u * 3u * tile_grid_rounds() ? batch : 256u * 3u * tile_grid_rounds());
     const unsigned b = (unsigned)batch;
@@ -390,7 +393,10 @@ hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {
+        (void)hipFreeAsync(ws, stream);
+        return e;
+    }
     const int nt = (n + 15) / 16;
     const unsigned occ = sizeof(T) == 8 ? 2u : 3u;
     const unsigned grid = (unsigned)(batch < 256u * occ * tile_grid_rounds() ? batch : 256u * occ * tile_grid_rounds());

@@ -114,6 +114,42 @@ __device__ __forceinline__ void gather_zero_tile_row(typename TileGeo<T>::vec4 (
 #undef TP_A
 }
 
+// v_permlane32_swap / v_permlane16_swap (gfx950) on one scalar of the tile type: rows of 32 (16) lanes; the odd rows of `a`
+// change places with the even rows of `b`.
+template <bool WIDE>
+__device__ __forceinline__ void lane_rows_swap(unsigned &a, unsigned &b)
+{
+    if constexpr (WIDE) {
+        auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        a = r[0], b = r[1];
+    } else {
+        auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        a = r[0], b = r[1];
+    }
+}
+template <bool WIDE>
+__device__ __forceinline__ void lane_rows_swap(float &a, float &b)
+{
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    lane_rows_swap<WIDE>(ua, ub);
+    a = __uint_as_float(ua), b = __uint_as_float(ub);
+}
+template <bool WIDE>
+__device__ __forceinline__ void lane_rows_swap(double &a, double &b)
+{
+    unsigned long long xa = (unsigned long long)__double_as_longlong(a), xb = (unsigned long long)__double_as_longlong(b);
+    unsigned alo = (unsigned)xa, ahi = (unsigned)(xa >> 32), blo = (unsigned)xb, bhi = (unsigned)(xb >> 32);
+    lane_rows_swap<WIDE>(alo, blo);
+    lane_rows_swap<WIDE>(ahi, bhi);
+    a = __longlong_as_double((long long)(((unsigned long long)ahi << 32) | alo));
+    b = __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
+}
+
+template <int V>
+struct IntC {
+    static constexpr int value = V;
+};
+
 template <class T, int NT, bool FULL>
 __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
                                               int *work_count, int *work_list, T *lds, unsigned char *tab)
@@ -122,8 +158,7 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
     typedef typename G::vec4 vec4;
     constexpr int N = 16 * NT;
     T *const panel = lds;        // [64][4]  the four pivot columns, one row per lane
-    T *const lmat = lds + 256;   // [64][4]  multipliers L_i (pivot lanes: -U^-1 rows)
-    T *const bbuf = lds + 512;   // [4][N]   the four pivot rows in B-operand order
+    T *const bbuf = lds + 256;   // [4][N]   the four pivot rows in B-operand order
     unsigned char *const rowaddr = tab, *const coladdr = tab + 64;
     const int l = threadIdx.x;
     // LDS byte address of this lane's element of pivot row 0 in bbuf (ds_write in gather_zero_tile_row)
@@ -154,172 +189,180 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
 
         bool used = lr >= N;  // rows that may still become pivots: false. Lanes beyond N hold no row.
         int bad = 0;
+        T aop[NT], bop[NT];  // operands of the block step whose MFMAs are still owed
 
+        // One pipeline turn = everything block nb = (tile column tKn [compile time], block rKn inside it [run time]) needs
+        // before its MFMAs, interleaved with the MFMAs of the PREVIOUS block (look-ahead, as in tile_kernels.inc):
+        //   1. previous block's update of tile column tKn (it holds the pivot columns of block nb)
+        //   2. the four pivot columns -> LDS; one row per lane back
+        //   3. pivot search + in-place Gauss-Jordan of the n x 4 panel, 12 stages, the other NT (NT-1) MFMAs of the
+        //      previous block pinned between them: while a 64-cycle MFMA runs, the scalar half of a stage (reductions,
+        //      v_readlane results, ff1, waits) proceeds
+        //   4. A operand through LDS (row i of the finished panel IS Aop[i,:]), B operand gather, C zeroing
+        auto turn = [&](auto tKc, int rKn, auto firstc) {
+            constexpr int tKn = decltype(tKc)::value;
+            constexpr bool first = decltype(firstc)::value != 0;
+            constexpr int NB = first ? 0 : NT * (NT - 1);
+            const bool panel_lane = G::blk(c) == rKn;
+            if (!first) {
 #pragma unroll
-        for (int tK = 0; tK < NT; ++tK) {
-#pragma nounroll
-            for (int rK = 0; rK < 4; ++rK) {
-                const bool panel_lane = G::blk(c) == rK;
-                // ---- A. the four pivot columns -> LDS, [row slot][4]
-                if (panel_lane) {
+                for (int ti = 0; ti < NT; ++ti) acc[ti][tKn] = G::mfma(aop[ti], bop[tKn], acc[ti][tKn]);
+            }
+            int pend = 0;  // folds to a literal: everything here is fully unrolled
+            auto issue_b = [&](int count) {
 #pragma unroll
-                    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) panel[(16 * ti + G::trow(r, q)) * 4 + G::piv(c)] = acc[ti][tK][r];
-                }
-                wave_lds_sync();
-                // ---- B. pivot search + elimination of the panel, lane = row slot
-                const vec4 wv = *reinterpret_cast<const vec4 *>(&panel[lr * 4]);
-                T w0 = wv[0], w1 = wv[1], w2 = wv[2], w3 = wv[3];
-                int pv = 0;  // lane t holds the row slot of pivot t
-                auto pick = [&](T wk, int t) -> int {
-                    const bool cand = !used;
-                    const unsigned key = cand ? magkey(wk) : 0u;
-                    const unsigned mx = wave_max_u32(key);
-                    if (key_bad(T(0), mx) && bad == 0) bad = 4 * (4 * tK + rK) + t + 1;
-                    const unsigned long long vote = __ballot(cand && key == mx);
-                    const int p = vote ? (int)__builtin_ctzll(vote) : 0;
-                    used = used || (lr == p);
-                    pv = (lr == t) ? p : pv;
-                    return p;
-                };
-                // step 0
-                const int p0 = pick(w0, 0);
-                const T u00 = lane_value(w0, p0), u01 = lane_value(w1, p0), u02 = lane_value(w2, p0), u03 = lane_value(w3, p0);
-                const T r0 = rcp_full(u00);
-                T L0 = (lr == p0) ? (T)1 : w0 * r0;
-                w1 = fma_t(-L0, u01, w1), w2 = fma_t(-L0, u02, w2), w3 = fma_t(-L0, u03, w3);
-                // step 1
-                const int p1 = pick(w1, 1);
-                const T d10 = lane_value(L0, p1);
-                const T u11 = lane_value(w1, p1), u12 = lane_value(w2, p1), u13 = lane_value(w3, p1);
-                const T r1 = rcp_full(u11);
-                T L1 = (lr == p1) ? (T)1 : w1 * r1;
-                w2 = fma_t(-L1, u12, w2), w3 = fma_t(-L1, u13, w3);
-                // step 2
-                const int p2 = pick(w2, 2);
-                const T d20 = lane_value(L0, p2), d21 = lane_value(L1, p2);
-                const T u22 = lane_value(w2, p2), u23 = lane_value(w3, p2);
-                const T r2 = rcp_full(u22);
-                T L2 = (lr == p2) ? (T)1 : w2 * r2;
-                w3 = fma_t(-L2, u23, w3);
-                // step 3
-                const int p3 = pick(w3, 3);
-                const T d30 = lane_value(L0, p3), d31 = lane_value(L1, p3), d32 = lane_value(L2, p3);
-                const T u33 = lane_value(w3, p3);
-                const T r3 = rcp_full(u33);
-                T L3 = (lr == p3) ? (T)1 : w3 * r3;
-                // U^-1 (upper triangular, wave-uniform); pivot lane t publishes -U^-1[t,:] in place of its L row
-                const T i23 = -(u23 * r3) * r2;
-                const T i12 = -(u12 * r2) * r1;
-                const T i13 = -fma_t(u12, i23, u13 * r3) * r1;
-                const T i01 = -(u01 * r1) * r0;
-                const T i02 = -fma_t(u01, i12, u02 * r2) * r0;
-                const T i03 = -fma_t(u01, i13, fma_t(u02, i23, u03 * r3)) * r0;
-                {
-                    vec4 lv;
-                    lv[0] = L0, lv[1] = L1, lv[2] = L2, lv[3] = L3;
-                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = lv;
-                }
-                wave_lds_sync();
-                if (lr == p0) {
-                    vec4 v;
-                    v[0] = -r0, v[1] = -i01, v[2] = -i02, v[3] = -i03;
-                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = v;
-                }
-                if (lr == p1) {
-                    vec4 v;
-                    v[0] = (T)0, v[1] = -r1, v[2] = -i12, v[3] = -i13;
-                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = v;
-                }
-                if (lr == p2) {
-                    vec4 v;
-                    v[0] = (T)0, v[1] = (T)0, v[2] = -r2, v[3] = -i23;
-                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = v;
-                }
-                if (lr == p3) {
-                    vec4 v;
-                    v[0] = (T)0, v[1] = (T)0, v[2] = (T)0, v[3] = -r3;
-                    *reinterpret_cast<vec4 *>(&lmat[lr * 4]) = v;
-                }
-                // permutation tables: column slot j_t was eliminated with row slot p_t
-                if (lr < 4) {
-                    const int j = 16 * tK + G::pcol(rK, lr);
-                    coladdr[j] = (unsigned char)pv;
-                    rowaddr[pv] = (unsigned char)j;
-                }
-                // L_D y = e_q: column q of L_D^-1 (per lane group)
-                const T y0 = (q == 0) ? (T)1 : (T)0;
-                const T y1 = fma_t(-d10, y0, (q == 1) ? (T)1 : (T)0);
-                const T y2 = fma_t(-d21, y1, fma_t(-d20, y0, (q == 2) ? (T)1 : (T)0));
-                const T y3 = fma_t(-d32, y2, fma_t(-d31, y1, fma_t(-d30, y0, (q == 3) ? (T)1 : (T)0)));
-                wave_lds_sync();
-                // ---- C. A operand: aop[ti] = Aop[16 ti + c][q] = -(L_i . y)
-                T aop[NT], bop[NT];
-#pragma unroll
-                for (int ti = 0; ti < NT; ++ti) {
-                    const vec4 lv = *reinterpret_cast<const vec4 *>(&lmat[(16 * ti + c) * 4]);
-                    aop[ti] = -fma_t(lv[3], y3, fma_t(lv[2], y2, fma_t(lv[1], y1, lv[0] * y0)));
-                }
-                // ---- D. B operand: the four pivot rows through LDS (and zero them in C)
-#pragma nounroll
-                for (int t = 0; t < 4; ++t) {
-                    const int s = __builtin_amdgcn_readlane(pv, t);
-                    const int loc = s & 15;
-                    const int pos = 4 * (s >> 4) + G::slot_r(loc);  // wave-uniform: 4 * tile row + register
-                    const unsigned long long mask = __ballot(q == G::slot_q(loc));
-                    const unsigned addr = bb_lane + (unsigned)(t * N * (int)sizeof(T));
-                    gather_zero_tile_row<T, NT, 0>(acc, addr, pos, mask);
-                    if constexpr (NT > 1) gather_zero_tile_row<T, NT, 1>(acc, addr, pos, mask);
-                    if constexpr (NT > 2) gather_zero_tile_row<T, NT, 2>(acc, addr, pos, mask);
-                    if constexpr (NT > 3) gather_zero_tile_row<T, NT, 3>(acc, addr, pos, mask);
-                }
-                wave_lds_sync();
-#pragma unroll
-                for (int tj = 0; tj < NT; ++tj) bop[tj] = bbuf[q * N + 16 * tj + c];
-                // pivot columns: I_4 in B, zero in C (the MFMA then leaves Aop there)
-                bop[tK] = panel_lane ? ((G::piv(c) == q) ? (T)1 : (T)0) : bop[tK];
-                {
-                    // EXEC narrowed to the pivot-column lanes (written as a C++ select hipcc branches and copies the
-                    // tile column: see tile4_impl.hpp)
-                    const unsigned long long zmask = __ballot(panel_lane);
-#pragma unroll
-                    for (int ti = 0; ti < NT; ++ti) {
-                        unsigned long long save;
-                        if constexpr (sizeof(T) == 8)
-                            asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
-                                         "v_mov_b64_e32 %0, 0\n\t"
-                                         "v_mov_b64_e32 %1, 0\n\t"
-                                         "v_mov_b64_e32 %2, 0\n\t"
-                                         "v_mov_b64_e32 %3, 0\n\t"
-                                         "s_nop 1\n\t"
-                                         "s_mov_b64 exec, %[save]"
-                                         : "+v"(acc[ti][tK][0]), "+v"(acc[ti][tK][1]), "+v"(acc[ti][tK][2]), "+v"(acc[ti][tK][3]),
-                                           [save] "=&s"(save)
-                                         : [mask] "s"(zmask)
-                                         : "scc");
-                        else
-                            asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
-                                         "v_mov_b32_e32 %0, 0\n\t"
-                                         "v_mov_b32_e32 %1, 0\n\t"
-                                         "v_mov_b32_e32 %2, 0\n\t"
-                                         "v_mov_b32_e32 %3, 0\n\t"
-                                         "s_nop 1\n\t"
-                                         "s_mov_b64 exec, %[save]"
-                                         : "+v"(acc[ti][tK][0]), "+v"(acc[ti][tK][1]), "+v"(acc[ti][tK][2]), "+v"(acc[ti][tK][3]),
-                                           [save] "=&s"(save)
-                                         : [mask] "s"(zmask)
-                                         : "scc");
+                for (int z = 0; z < count; ++z) {
+                    if (pend < NB) {
+                        const int tjx = pend / NT, ti = pend % NT;
+                        const int tj = tjx + (tjx >= tKn ? 1 : 0);
+                        acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
+                        ++pend;
                     }
                 }
-                // ---- E. rank-4 update of every tile
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            issue_b(2);  // cover the latency of (1) before its results are staged
+            wave_lds_sync();
+            if (panel_lane) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-                    for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
-                wave_lds_sync();
+                    for (int r = 0; r < 4; ++r) panel[(16 * ti + G::trow(r, q)) * 4 + G::piv(c)] = acc[ti][tKn][r];
             }
+            wave_lds_sync();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_b(NT >= 4 ? 2 : 0);  // the LDS turn-around of the panel runs under these
+            const vec4 wv = *reinterpret_cast<const vec4 *>(&panel[lr * 4]);
+            T w[4] = {wv[0], wv[1], wv[2], wv[3]};
+            T u[4] = {};
+            T rp = (T)0;
+            int p = 0, pv = 0;  // current pivot row slot; lane t of pv holds the slot of pivot t
+            constexpr int NS = 12;
+            constexpr int NLEAD = NT >= 4 ? 4 : 2;  // MFMAs already issued around the panel staging
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int t = st / 3;
+                issue_b(((NB - NLEAD) * (st + 1)) / NS - ((NB - NLEAD) * st) / NS);
+                if (st % 3 == 0) {
+                    // largest |w_t| over the rows not used yet; lowest row slot on ties
+                    const unsigned key = used ? 0u : magkey(w[t]);
+                    const unsigned mx = wave_max_u32(key);
+                    if (key_bad(T(0), mx) && bad == 0) bad = 1;
+                    // key == mx != 0 implies a candidate row (the others carry key 0; mx == 0 is the singular case)
+                    const unsigned long long vote = __builtin_amdgcn_uicmp(key, mx, 32 /* ICMP_EQ */);
+                    p = vote ? (int)__builtin_ctzll(vote) : 0;
+                    used = used || (lr == p);
+                    pv = (lr == t) ? p : pv;
+                } else if (st % 3 == 1) {
+                    // the pivot row's four panel values as scalars, and the reciprocal of the pivot
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = lane_value(w[j], p);
+                    rp = rcp_full(u[t]);
+                } else {
+                    // in-place Gauss-Jordan step of the panel: column t becomes the inverse column
+                    const T f = -(w[t] * rp);
+                    const bool me = lr == p;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j == t) continue;
+                        const T piv_j = u[j] * rp;  // wave-uniform
+                        w[j] = me ? piv_j : fma_t(f, u[j], w[j]);
+                    }
+                    w[t] = me ? rp : f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            issue_b(NB);  // whatever is left (NT < 3)
+            // Row i of the finished panel is Aop[i, 0..3] (pivot rows: their row of D^-1) and sits in lane i; lane (q, c) needs
+            // Aop[16 ti + c][q] = component q of lane group ti: a 4 x 4 transpose of (w0..w3) across the four lane groups,
+            // two rounds of v_permlane32_swap / v_permlane16_swap -- no LDS round trip.
+            lane_rows_swap<true>(w[0], w[2]);
+            lane_rows_swap<true>(w[1], w[3]);
+            lane_rows_swap<false>(w[0], w[1]);
+            lane_rows_swap<false>(w[2], w[3]);
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) aop[ti] = w[ti];
+            // permutation tables: column slot j_t was eliminated with row slot p_t
+            if (lr < 4) {
+                const int j = 16 * tKn + G::pcol(rKn, lr);
+                coladdr[j] = (unsigned char)pv;
+                rowaddr[pv] = (unsigned char)j;
+            }
+            // B operand: the four pivot rows through LDS (and zero them in C)
+#pragma nounroll
+            for (int t = 0; t < 4; ++t) {
+                const int s = __builtin_amdgcn_readlane(pv, t);
+                const int loc = s & 15;
+                const int pos = 4 * (s >> 4) + G::slot_r(loc);  // wave-uniform: 4 * tile row + register
+                const unsigned long long mask = 0xffffull << (16 * G::slot_q(loc));
+                const unsigned addr = bb_lane + (unsigned)(t * N * (int)sizeof(T));
+                gather_zero_tile_row<T, NT, 0>(acc, addr, pos, mask);
+                if constexpr (NT > 1) gather_zero_tile_row<T, NT, 1>(acc, addr, pos, mask);
+                if constexpr (NT > 2) gather_zero_tile_row<T, NT, 2>(acc, addr, pos, mask);
+                if constexpr (NT > 3) gather_zero_tile_row<T, NT, 3>(acc, addr, pos, mask);
+            }
+            // pivot columns: zero in C (the MFMA then leaves Aop there) -- placed here, it runs under the gather's LDS turn-around
+            {
+                // EXEC narrowed to the pivot-column lanes (written as a C++ select hipcc branches and copies the
+                // tile column: see tile4_impl.hpp)
+                const unsigned long long zmask = __ballot(panel_lane);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    unsigned long long save;
+                    if constexpr (sizeof(T) == 8)
+                        asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
+                                     "v_mov_b64_e32 %0, 0\n\t"
+                                     "v_mov_b64_e32 %1, 0\n\t"
+                                     "v_mov_b64_e32 %2, 0\n\t"
+                                     "v_mov_b64_e32 %3, 0\n\t"
+                                     "s_nop 1\n\t"
+                                     "s_mov_b64 exec, %[save]"
+                                     : "+v"(acc[ti][tKn][0]), "+v"(acc[ti][tKn][1]), "+v"(acc[ti][tKn][2]), "+v"(acc[ti][tKn][3]),
+                                       [save] "=&s"(save)
+                                     : [mask] "s"(zmask)
+                                     : "scc");
+                    else
+                        asm volatile("s_and_saveexec_b64 %[save], %[mask]\n\t"
+                                     "v_mov_b32_e32 %0, 0\n\t"
+                                     "v_mov_b32_e32 %1, 0\n\t"
+                                     "v_mov_b32_e32 %2, 0\n\t"
+                                     "v_mov_b32_e32 %3, 0\n\t"
+                                     "s_nop 1\n\t"
+                                     "s_mov_b64 exec, %[save]"
+                                     : "+v"(acc[ti][tKn][0]), "+v"(acc[ti][tKn][1]), "+v"(acc[ti][tKn][2]), "+v"(acc[ti][tKn][3]),
+                                       [save] "=&s"(save)
+                                     : [mask] "s"(zmask)
+                                     : "scc");
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) bop[tj] = bbuf[q * N + 16 * tj + c];
+            // pivot columns: I_4 in B
+            bop[tKn] = panel_lane ? ((G::piv(c) == q) ? (T)1 : (T)0) : bop[tKn];
+        };
+
+        turn(IntC<0>(), 0, IntC<1>());
+#pragma nounroll
+        for (int rK = 1; rK < 4; ++rK) turn(IntC<0>(), rK, IntC<0>());
+        if constexpr (NT > 1) {
+#pragma nounroll
+            for (int rK = 0; rK < 4; ++rK) turn(IntC<1>(), rK, IntC<0>());
         }
+        if constexpr (NT > 2) {
+#pragma nounroll
+            for (int rK = 0; rK < 4; ++rK) turn(IntC<2>(), rK, IntC<0>());
+        }
+        if constexpr (NT > 3) {
+#pragma nounroll
+            for (int rK = 0; rK < 4; ++rK) turn(IntC<3>(), rK, IntC<0>());
+        }
+        // the last block's update
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
 
         if (bad == 0) {
             // F[i][j] = inverse[rowaddr[i]][coladdr[j]] (see the header): W = A^T is stored as W[a][b] at a*n + b
@@ -346,10 +389,10 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
 }
 
 template <int NT, bool FULL>
-__global__ __launch_bounds__(64, 2) void matinv_gj_tilep_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
+__global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
                                                             unsigned batch, int *work_count, int *work_list)
 {
-    __shared__ __attribute__((aligned(16))) double lds[512 + 4 * 16 * NT];
+    __shared__ __attribute__((aligned(16))) double lds[256 + 4 * 16 * NT];
     __shared__ unsigned char tab[128];
     gj_tilep_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab);
 }
@@ -358,7 +401,7 @@ template <int NT, bool FULL>
 __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n_rt,
                                                             unsigned batch, int *work_count, int *work_list)
 {
-    __shared__ __attribute__((aligned(16))) float lds[512 + 4 * 16 * NT];
+    __shared__ __attribute__((aligned(16))) float lds[256 + 4 * 16 * NT];
     __shared__ unsigned char tab[128];
     gj_tilep_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab);
 }

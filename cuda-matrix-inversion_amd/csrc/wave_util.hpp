@@ -13,17 +13,30 @@ __device__ __forceinline__ unsigned dppu(unsigned v)
     return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-// maximum over the 64 lanes, wave-uniform (SGPR)
+// maximum over the 64 lanes, wave-uniform (SGPR). Six DPP-modified v_max_u32 (quad swaps, half-row and row mirrors: every
+// lane of a row of 16 then holds the row's maximum; row_bcast:15 / row_bcast:31 carry it across the rows into lane 63) and
+// ONE v_readlane. Written through __builtin_amdgcn_update_dpp hipcc emits v_mov + v_mov_dpp + v_max per step and four
+// v_readlane + a scalar max tree: 19 VALU instructions instead of 7. The s_nop 1 are the two wait states a DPP source
+// needs after the VALU instruction that wrote it (hipcc pads nothing inside an asm block).
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
-    v = max(v, dppu<DPPR_QUAD_XOR1>(v));
-    v = max(v, dppu<DPPR_QUAD_XOR2>(v));
-    v = max(v, dppu<DPPR_ROW_HALF_MIRROR>(v));
-    v = max(v, dppu<DPPR_ROW_MIRROR>(v));  // every lane of a row of 16 now holds that row's maximum
-    const unsigned m0 = __builtin_amdgcn_readlane(v, 0), m1 = __builtin_amdgcn_readlane(v, 16);
-    const unsigned m2 = __builtin_amdgcn_readlane(v, 32), m3 = __builtin_amdgcn_readlane(v, 48);
-    const unsigned a = m0 > m1 ? m0 : m1, b = m2 > m3 ? m2 : m3;
-    return a > b ? a : b;
+    unsigned m;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %[v], %[v], %[v] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %[v], %[v], %[v] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %[v], %[v], %[v] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %[v], %[v], %[v] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %[v], %[v], %[v] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %[v], %[v], %[v] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_readlane_b32 %[m], %[v], 63"
+                 : [v] "+v"(v), [m] "=s"(m));
+    return m;
 }
 
 __device__ __forceinline__ unsigned magkey(double v) { return (unsigned)(__double_as_longlong(v) >> 32) & 0x7fffffffu; }

@@ -74,7 +74,7 @@ typedef enum {
  *                every kernel reads a whole matrix before writing it); partial overlap is undefined.
  *   dInfo   out: optional int[batch] (device). 0 = ok; k+1 = no usable pivot at elimination step k
  *                (Gauss-Jordan: singular) or leading minor k+1 not positive (Cholesky: not SPD).
- *                The output matrix is unspecified for info != 0.
+ *                For info != 0 the output matrix is filled with NaN (never left half-written).
  *   stream     : hipStream_t as void* (NULL = default stream). Asynchronous.
  */
 int matinv_inverse_batched(int algo, int dtype, int n, const void *dA, size_t strideA, void *dAinv,
@@ -112,6 +112,17 @@ int matinv_mean_batched_host(int dtype, int n, const void *hAs, const void *hBs,
                              void *hMeans, size_t batch, int *info);
 int matinv_variance_batched_host(int dtype, int n, const void *hAs, const void *hBs, const void *hCs, const void *hEs,
                                  void *hVars, size_t batch, int *info);
+
+/* The reference's batch allocator (batchedCudaMalloc, src/helper.cu:103-118; declared include/helper_gpu.h:4): ONE pitched
+ * device allocation of batchSize rows of arraySize BYTES; devArrayPtr (host array of batchSize pointers, caller-owned)
+ * receives the row addresses, *pitch the row pitch in bytes (a multiple of 256, so of sizeof(double)). The tables are what
+ * the *_batched_device entry points of inverse_gpu.h take. matinv_batched_free releases the block behind devArrayPtr[0]. */
+int matinv_batched_malloc(void **devArrayPtr, size_t *pitch, size_t arraySize, int batchSize);
+int matinv_batched_free(void **devArrayPtr);
+/* cudaMemcpy2D as the reference uses it on those blocks (src/gauss_bench.cu:165-170,244): width bytes x height rows,
+ * blocking. toDevice != 0: host -> device, else device -> host. Lets a plain-C caller stage data without HIP headers. */
+int matinv_memcpy_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, int toDevice);
+int matinv_device_synchronize(void);
 
 const char *matinv_last_error(void);
 int matinv_abi_version(void);

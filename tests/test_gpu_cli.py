@@ -63,6 +63,31 @@ def test_detailed_logging_lines():
     assert f[1] == "100" and f[2] == "8" and float(f[3]) >= 0 and int(f[4]) >= 0
 
 
+def test_pipeline_logging_keys_are_the_references():
+    """src/gauss_bench.cu:151-156,250-255,298-303,394-399: the six phase keys results/generate_plots.m:69-76 sums."""
+    p = subprocess.run([os.path.join(HOST, "gauss_bench"), os.path.join(REFDATA, "gaussian_100_8x8"), "1", "1"],
+                       capture_output=True, text=True, env=dict(os.environ, MATINV_DETAILED_LOGGING="1"))
+    assert p.returncode == 0, p.stderr
+    keys = [ln.split(",")[0] for ln in p.stdout.splitlines() if "," in ln]
+    for what in ("mean", "variance"):
+        for phase in ("mem_htod", "add", "inv", "mul", "dot", "mem_dtoh"):
+            assert f"calculate_{what}_gpu_{phase}" in keys, (what, phase, keys)
+    for k in ("means_cpu", "variances_cpu", "means_gpu", "variances_gpu"):
+        assert k in keys, (k, keys)
+
+
+@pytest.mark.parametrize("exe", ["device_table_test", "device_table_test_f32"])
+@pytest.mark.parametrize("n,batch", [(8, 100), (32, 257), (64, 1000), (100, 50), (150, 9)])
+def test_device_table_call_sequence_in_c(exe, n, batch):
+    """batchedCudaMalloc + cudaMemcpy2D + inverse_lu_cuda_batched_device exactly as src/gauss_bench.cu:68-78,160-170 does,
+    in plain C, on general matrices, against the host LU."""
+    lines = run(exe, str(n), str(batch))
+    assert lines[-1].startswith(f"device_table_test n={n} batch={batch} pitch="), lines
+    pitch = int(lines[-1].split("pitch=")[1].split()[0])
+    esz = 4 if exe.endswith("f32") else 8
+    assert pitch >= n * n * esz and pitch % 256 == 0
+
+
 @pytest.mark.parametrize("n,k", [(64, 40), (128, 12)])
 def test_sweep_sizes_missing_from_the_reference_tree(tmp_path, n, k):
     """The reference's `make run-inverse-bench` / `run-gauss-bench` sweeps go up to 128x128, but its 64 / 128 fixtures are
