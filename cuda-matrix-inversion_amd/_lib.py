@@ -34,7 +34,7 @@ NATIVE_NAMES = [
     "matinv_mean_batched", "matinv_variance_batched", "matinv_inverse_batched_host", "matinv_mean_batched_host",
     "matinv_variance_batched_host", "matinv_last_error",
     "matinv_abi_version", "matinv_release_cache", "matinv_batched_malloc", "matinv_batched_free", "matinv_memcpy_2d",
-    "matinv_device_synchronize",
+    "matinv_device_synchronize", "matinv_tile_stats",
 ]
 
 
@@ -81,6 +81,15 @@ def lib() -> ctypes.CDLL:
     for f in (L.matinv_mean_batched_host, L.matinv_variance_batched_host):
         f.restype = ci
         f.argtypes = [ci, ci, vp, vp, vp, vp, vp, sz, vp]
+    L.matinv_tile_stats.restype = ci
+    L.matinv_tile_stats.argtypes = [vp, vp, vp, vp]
+    L.matinv_batched_malloc.restype = ci
+    L.matinv_batched_malloc.argtypes = [vp, vp, sz, ci]
+    L.matinv_batched_free.restype = ci
+    L.matinv_batched_free.argtypes = [vp]
+    L.matinv_memcpy_2d.restype = ci
+    L.matinv_memcpy_2d.argtypes = [vp, sz, vp, sz, sz, sz, ci]
+    L.matinv_device_synchronize.restype = ci
     L.matinv_last_error.restype = ctypes.c_char_p
     L.matinv_abi_version.restype = ci
     L.matinv_release_cache.restype = ci

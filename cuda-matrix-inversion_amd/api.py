@@ -183,6 +183,13 @@ mean_batched = calcluateMean
 variance_batched = calcluateVariance
 
 
+def tile_stats() -> dict:
+    """matinv_tile_stats: how the adaptive natural-order / pivoting dispatch of the tile family went since load."""
+    v = [ctypes.c_ulonglong(0) for _ in range(4)]
+    _lib.check(_lib.lib().matinv_tile_stats(*[ctypes.byref(x) for x in v]))
+    return dict(zip(("natural_launches", "pivot_launches", "last_rejected", "last_batch"), (int(x.value) for x in v)))
+
+
 def select_kernel(algo: int, dtype, n: int) -> int:
     code = dtype if isinstance(dtype, int) else _np_dtype_code(dtype)
     k = _lib.lib().matinv_select_kernel(algo, code, n)

@@ -588,6 +588,18 @@ int matinv_memcpy_2d(void *dst, size_t dpitch, const void *src, size_t spitch, s
     return MATINV_OK;
 }
 
+// how the adaptive Gauss-Jordan dispatch of the tile family went (tile_kernels.inc "natural order or pivot search?")
+int matinv_tile_stats(unsigned long long *natural_launches, unsigned long long *pivot_launches, unsigned long long *last_rejected,
+                      unsigned long long *last_batch)
+{
+    const TileStats s = tile_stats();
+    if (natural_launches) *natural_launches = s.natural_launches;
+    if (pivot_launches) *pivot_launches = s.pivot_launches;
+    if (last_rejected) *last_rejected = s.last_rejected;
+    if (last_batch) *last_batch = s.last_batch;
+    return MATINV_OK;
+}
+
 int matinv_device_synchronize(void)
 {
     hipError_t e = hipDeviceSynchronize();

@@ -9,4 +9,11 @@ hipError_t launch_gj_tilep<float>(int n, BatchRef<const float> A, BatchRef<float
     return launch_tilep<float>(n, A, X, batch, info, stream);
 }
 
+template <>
+hipError_t launch_gj_tilep_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
+                                           const int *in_list, int *scratch, int *info, hipStream_t stream)
+{
+    return launch_tilep_worklist<float>(n, A, X, batch, in_count, in_list, scratch, info, stream);
+}
+
 }  // namespace matinv

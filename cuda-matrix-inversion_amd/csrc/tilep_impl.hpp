@@ -152,7 +152,8 @@ struct IntC {
 
 template <class T, int NT, bool FULL>
 __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
-                                              int *work_count, int *work_list, T *lds, unsigned char *tab)
+                                              int *work_count, int *work_list, T *lds, unsigned char *tab,
+                                              const int *in_count = nullptr, const int *in_list = nullptr)
 {
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
@@ -165,7 +166,10 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
     typedef __attribute__((address_space(3))) T *lds_ptr;
     const unsigned bb_lane = (unsigned)(size_t)(lds_ptr)(bbuf + (l & 15));
 
-    for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
+    // work-list form (the matrices the natural-order kernel rejected): in_list[0 .. *in_count)
+    const unsigned todo = in_count ? (unsigned)*in_count : batch;
+    for (unsigned item = blockIdx.x; item < todo; item += gridDim.x) {
+        const unsigned mat = in_list ? (unsigned)in_list[item] : item;
         const T *A = Ain.at_uniform(mat);
         T *X = Xout.at_uniform(mat);
         int n = FULL ? N : n_rt;
@@ -390,20 +394,55 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
 
 template <int NT, bool FULL>
 __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
-                                                            unsigned batch, int *work_count, int *work_list)
+                                                            unsigned batch, int *work_count, int *work_list,
+                                                            const int *in_count, const int *in_list)
 {
     __shared__ __attribute__((aligned(16))) double lds[256 + 4 * 16 * NT];
     __shared__ unsigned char tab[128];
-    gj_tilep_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab);
+    gj_tilep_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab, in_count, in_list);
 }
 
 template <int NT, bool FULL>
 __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n_rt,
-                                                            unsigned batch, int *work_count, int *work_list)
+                                                            unsigned batch, int *work_count, int *work_list,
+                                                            const int *in_count, const int *in_list)
 {
     __shared__ __attribute__((aligned(16))) float lds[256 + 4 * 16 * NT];
     __shared__ unsigned char tab[128];
-    gj_tilep_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab);
+    gj_tilep_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab, in_count, in_list);
+}
+
+// Enqueue the kernel only. in_count / in_list != nullptr: work-list form (grid sized for the worst case, blocks beyond
+// the list exit at once). Singular matrices are appended to (out_count, out_list).
+template <class T>
+static hipError_t enqueue_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
+                                int *out_count, int *out_list, const int *in_count, const int *in_list)
+{
+    const int nt = (n + 15) / 16;
+    unsigned cap = 256u * 12u * tile_grid_rounds();
+    if (in_list && cap > 256u * 12u * 4u) cap = 256u * 12u * 4u;
+    const unsigned grid = (unsigned)(batch < cap ? batch : cap);
+    const unsigned b = (unsigned)batch;
+#define TP_LAUNCH(NT_)                                                                                                 \
+    if constexpr (sizeof(T) == 8) {                                                                                    \
+        if (n == 16 * NT_)                                                                                             \
+            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, out_count, out_list, in_count, in_list); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, out_count, out_list, in_count, in_list); \
+    } else {                                                                                                           \
+        if (n == 16 * NT_)                                                                                             \
+            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, out_count, out_list, in_count, in_list); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, out_count, out_list, in_count, in_list); \
+    }
+    switch (nt) {
+    case 1: TP_LAUNCH(1) break;
+    case 2: TP_LAUNCH(2) break;
+    case 3: TP_LAUNCH(3) break;
+    default: TP_LAUNCH(4) break;
+    }
+#undef TP_LAUNCH
+    return hipGetLastError();
 }
 
 template <class T>
@@ -419,34 +458,24 @@ static hipError_t launch_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t
         (void)hipFreeAsync(ws, stream);
         return e;
     }
-    const int nt = (n + 15) / 16;
-    const unsigned cap = 256u * 8u * tile_grid_rounds();
-    const unsigned grid = (unsigned)(batch < cap ? batch : cap);
-    const unsigned b = (unsigned)batch;
-#define TP_LAUNCH(NT_)                                                                                                 \
-    if constexpr (sizeof(T) == 8) {                                                                                    \
-        if (n == 16 * NT_)                                                                                             \
-            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
-        else                                                                                                           \
-            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
-    } else {                                                                                                           \
-        if (n == 16 * NT_)                                                                                             \
-            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
-        else                                                                                                           \
-            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, ws, ws + 1); \
-    }
-    switch (nt) {
-    case 1: TP_LAUNCH(1) break;
-    case 2: TP_LAUNCH(2) break;
-    case 3: TP_LAUNCH(3) break;
-    default: TP_LAUNCH(4) break;
-    }
-#undef TP_LAUNCH
-    e = hipGetLastError();
+    e = enqueue_tilep<T>(n, A, X, batch, info, stream, ws, ws + 1, nullptr, nullptr);
     // singular input only: the ROW kernel reports the exact step and NaN-fills the output
     if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
+}
+
+// the rejected matrices of the natural-order kernel (in_count, in_list), then the singular ones among them on the ROW kernel;
+// scratch = batch + 1 ints for the second list
+template <class T>
+static hipError_t launch_tilep_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count,
+                                        const int *in_list, int *scratch, int *info, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = enqueue_tilep<T>(n, A, X, batch, info, stream, scratch, scratch + 1, in_count, in_list);
+    if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, scratch, scratch + 1, info, stream);
+    return e;
 }
 
 }  // namespace matinv

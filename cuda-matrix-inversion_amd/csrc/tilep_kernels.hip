@@ -18,4 +18,11 @@ const char *name_gj_tilep(bool f64, int n)
     return buf;
 }
 
+template <>
+hipError_t launch_gj_tilep_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
+                                           const int *in_list, int *scratch, int *info, hipStream_t stream)
+{
+    return launch_tilep_worklist<double>(n, A, X, batch, in_count, in_list, scratch, info, stream);
+}
+
 }  // namespace matinv

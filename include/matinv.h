@@ -123,6 +123,14 @@ int matinv_batched_free(void **devArrayPtr);
  * blocking. toDevice != 0: host -> device, else device -> host. Lets a plain-C caller stage data without HIP headers. */
 int matinv_memcpy_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, int toDevice);
 int matinv_device_synchronize(void);
+/* Gauss-Jordan, 16 < n <= 64: the tile family chooses per launch between its natural-order kernel (pivots verified, not
+ * searched: the fast path of dominant / SPD batches; rejected matrices are redone by the pivoting kernel in the same stream)
+ * and its pivoting kernel (true partial pivoting inside the MFMA sweep), from the reject count of the last completed
+ * natural-order launch of that size. Counters since load: launches of either kind, and the reject count / batch of the last
+ * natural-order launch whose count has come back (call matinv_device_synchronize first for an exact figure). Any pointer
+ * may be NULL. MATINV_GJ_POLICY=natural|pivot pins the choice. */
+int matinv_tile_stats(unsigned long long *natural_launches, unsigned long long *pivot_launches, unsigned long long *last_rejected,
+                      unsigned long long *last_batch);
 
 const char *matinv_last_error(void);
 int matinv_abi_version(void);

@@ -21,7 +21,7 @@ torch = pytest.importorskip("torch")
 api = pkg("api")
 GJ, CH = api.ALGO_GAUSS_JORDAN, api.ALGO_CHOLESKY
 FAMILIES = {"auto": api.KERNEL_AUTO, "lds": api.KERNEL_LDS, "rowlane": api.KERNEL_ROWLANE, "tile": api.KERNEL_TILE,
-            "row": api.KERNEL_ROW}
+            "row": api.KERNEL_ROW, "tilep": api.KERNEL_TILEP}
 
 
 def dev(x):
@@ -149,6 +149,47 @@ def test_reference_fixtures_and_goldens(d, n, family, gold):
 def test_square_fixtures_pivoting(f, n, gold):
     a, _, _, _ = read_ref(f + ".mats")
     assert rel_err(gpu_inverse(a, n, GJ), gold[f + "/gj"], n) < 1e-10
+    if n <= 64:  # the pivoting MFMA tile kernel itself (the reference's general fixtures, tests/square_5_*.mats)
+        assert rel_err(gpu_inverse(a, n, GJ, api.KERNEL_TILEP), gold[f + "/gj"], n) < 1e-10
+
+
+@pytest.mark.parametrize("n", [20, 32, 50, 64])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tile_family_pivots_inside_the_kernel(n, dtype):
+    """General batches through the tile family: the first launch tries the natural order, every matrix it rejects is
+    redone by the PIVOTING MFMA kernel in the same stream (not by the lane-per-row kernel), and from the next launch on
+    the batch goes to the pivoting kernel directly (adaptive dispatch, matinv_tile_stats)."""
+    a = general_batch(n, 300, seed=77 + n).astype(dtype)
+    want, _ = oracle.inverse_batched(a.astype(np.float64), n, oracle.ALGO_GJ_PIVOT)
+    cond = max(np.linalg.cond(m) for m in as_mats(a.astype(np.float64), n))
+    tol = max(1e-10, 1e-15 * cond * n) if dtype == np.float64 else 1e-5 * cond
+    lib = pkg("_lib").lib()
+    b = spd_batch(n, 64, seed=5).astype(dtype)
+    for rep in range(34):  # whatever earlier tests left behind: at most 32 launches later the natural order is probed again
+        gpu_inverse(b, n, GJ, api.KERNEL_TILE)
+    assert lib.matinv_device_synchronize() == 0
+    s0 = api.tile_stats()
+    assert s0["last_rejected"] == 0
+    for rep in range(3):
+        got, info = gpu_inverse(a, n, GJ, api.KERNEL_TILE, want_info=True)
+        assert not info.any()
+        err = rel_err(got.astype(np.float64), want, n) if dtype == np.float64 else \
+            np.linalg.norm(got.astype(np.float64) - want) / np.linalg.norm(want)
+        assert err < tol, (rep, err, tol)
+        assert lib.matinv_device_synchronize() == 0
+    s1 = api.tile_stats()
+    assert s1["natural_launches"] == s0["natural_launches"] + 1, (s0, s1)  # the first launch tries the natural order
+    assert s1["pivot_launches"] == s0["pivot_launches"] + 2, (s0, s1)  # ... then straight to the pivoting kernel
+    assert s1["last_rejected"] >= 0.9 * 300 and s1["last_batch"] == 300
+    # an SPD batch afterwards flips the guess back after one natural-order launch
+    wantb, _ = oracle.inverse_batched(b.astype(np.float64), n, oracle.ALGO_GJ_PIVOT)
+    for rep in range(34):
+        gotb = gpu_inverse(b, n, GJ, api.KERNEL_TILE)
+    assert lib.matinv_device_synchronize() == 0
+    s2 = api.tile_stats()
+    assert s2["last_rejected"] == 0 and s2["last_batch"] == 64
+    errb = np.linalg.norm(gotb.astype(np.float64) - wantb) / np.linalg.norm(wantb)
+    assert errb < (1e-12 if dtype == np.float64 else 1e-4)
 
 
 def test_simplemean_cholesky_golden(gold):
