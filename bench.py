@@ -7,10 +7,12 @@ generated as R + R^T + n*I (tests/generate_inverse_matrices.m:9-18 of the refere
 north_star target ("inversions/s of 64x64 fp64 ... fraction of HBM roofline") is quoted on. `--workload` selects
 the other single-GPU configs (n16 = configs[1], chol64 = the Cholesky half of configs[2]).
 
-Multi-GPU (`--gpus N`, launched by torch.distributed.run, one rank per GPU): the batch shards by matrix index with
-no data-path collective (weak scaling: every rank inverts its own `--batch` matrices); value = matrices all ranks
-inverted / max-over-ranks time. The RCCL all-gather that reassembles results is timed separately and reported as
-`allgather_ms` (it is not part of the inversion path and not in `value`).
+Multi-GPU (`--gpus N`, launched by torch.distributed.run, one rank per GPU) = BASELINE.json configs[3] literally: a TOTAL
+batch of 1 000 000 64x64 fp64 matrices (`--total-batch`), block-partitioned over the ranks by `shard.partition`, every rank
+generating its own shard from its own seed; no data-path collective. value = total matrices / max-over-ranks time of the
+inversions alone. The RCCL all-gather over xGMI that reassembles the result on every rank (the only exchange the path
+has) is timed separately and reported as `allgather_ms` / `allgather_GBs` beside the per-link xGMI bound; it is not in
+`value`. `--batch B` instead gives every rank B matrices (weak scaling).
 
 Prints ONE JSON line on rank 0.
 """
@@ -33,9 +35,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 
 WORKLOADS = {
     # name: (n, algo, description)
-    "gj64": (64, "gj", "batch x 64x64 fp64 Gauss-Jordan (partial pivoting), SPD inputs, BASELINE configs[2]"),
+    "gj64": (64, "gj", "batch x 64x64 fp64 Gauss-Jordan, SPD inputs (natural-order pivots verified inside the MFMA sweep; a rejected matrix is redone with partial pivoting), BASELINE configs[2]"),
     "chol64": (64, "chol", "batch x 64x64 fp64 Cholesky inverse, SPD inputs, BASELINE configs[2]"),
-    "gj16": (16, "gj", "batch x 16x16 fp64 Gauss-Jordan (partial pivoting), SPD inputs, BASELINE configs[1]"),
+    "gj16": (16, "gj", "batch x 16x16 fp64 Gauss-Jordan (threshold partial pivoting), SPD inputs, BASELINE configs[1]"),
     "gj32": (32, "gj", "batch x 32x32 fp64 Gauss-Jordan"),
     "gj8": (8, "gj", "batch x 8x8 fp64 Gauss-Jordan"),
     "gj128": (128, "gj", "batch x 128x128 fp64 Gauss-Jordan"),
@@ -44,8 +46,10 @@ WORKLOADS = {
     "gj64g": (64, "gj", "batch x 64x64 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
     "gj32g": (32, "gj", "batch x 32x32 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
     "gj128g": (128, "gj", "batch x 128x128 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
+    "gj256g": (256, "gj", "batch x 256x256 fp64 blocked Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
+    "chol256": (256, "chol", "batch x 256x256 fp64 blocked Cholesky inverse, SPD inputs"),
 }
-GENERAL = {"gj64g", "gj32g", "gj128g"}
+GENERAL = {"gj64g", "gj32g", "gj128g", "gj256g"}
 
 
 def make_spd(n, batch, seed, device):
@@ -73,11 +77,21 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(n, algo_name, target_seconds=12.0):
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n, algo_name, target_seconds=9.0):
     """Oracle (oracle/liboracle.so, a C port of the reference's CPU algorithms) timed on this box's host cores,
-    OpenMP schedule(dynamic,8) over the batch as src/inverse.c:79 of the reference. Bounded sample."""
+    OpenMP schedule(dynamic,8) over the batch as src/inverse.c:79 of the reference. Two rows:
+    OMP threads = 8 (the reference's README.md:9 protocol) and = every core this process may use. Bounded sample."""
     import oracle
-    cores = usable_cores()
     algo = oracle.ALGO_GJ_PIVOT if algo_name == "gj" else oracle.ALGO_CHOLESKY
     rng = np.random.default_rng(0)
 
@@ -85,24 +99,33 @@ def cpu_baseline(n, algo_name, target_seconds=12.0):
         r = rng.random((k, n, n))
         return (r + r.transpose(0, 2, 1) + n * np.eye(n)).reshape(-1)
 
-    probe = sample(max(cores * 16, 256))
-    oracle.inverse_batched(probe, n, algo, threads=cores)  # warm-up (thread pool, page faults)
-    t0 = time.perf_counter()
-    oracle.inverse_batched(probe, n, algo, threads=cores)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    rate = (probe.size // (n * n)) / dt
-    # a sample of at most ~1 GB, inverted `passes` times back to back so that the timed CPU work is ~target_seconds
-    k = int(min(max(rate * target_seconds, 1024), 1e9 / (n * n * 8)))
-    passes = max(1, int(round(rate * target_seconds / k)))
-    a = sample(k)
-    t0 = time.perf_counter()
-    for _ in range(passes):
-        oracle.inverse_batched(a, n, algo, threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": k * passes / dt, "unit": "inversions/s", "cores": cores, "kind": "port",
-            "sample": f"{k} SPD {n}x{n} fp64 matrices x {passes} passes, oracle "
-                      f"{'Gauss-Jordan partial pivot' if algo_name == 'gj' else 'Cholesky'}"
-                      f" (C, OpenMP {cores} threads, schedule(dynamic,8)), {dt:.1f} s"}
+    def timed(cores):
+        probe = sample(max(cores * 16, 256))
+        oracle.inverse_batched(probe, n, algo, threads=cores)  # warm-up (thread pool, page faults)
+        t0 = time.perf_counter()
+        oracle.inverse_batched(probe, n, algo, threads=cores)
+        dt = max(time.perf_counter() - t0, 1e-6)
+        rate = (probe.size // (n * n)) / dt
+        # a sample of at most ~1 GB, inverted `passes` times back to back so that the timed CPU work is ~target_seconds
+        k = int(min(max(rate * target_seconds, 1024), 1e9 / (n * n * 8)))
+        passes = max(1, int(round(rate * target_seconds / k)))
+        a = sample(k)
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            oracle.inverse_batched(a, n, algo, threads=cores)
+        dt = time.perf_counter() - t0
+        return k * passes / dt, f"{k} SPD {n}x{n} fp64 matrices x {passes} passes, {dt:.1f} s"
+
+    allc = usable_cores()
+    v_all, s_all = timed(allc)
+    out = {"value": v_all, "unit": "inversions/s", "cores": allc, "kind": "port",
+           "sample": s_all + f"; oracle {'Gauss-Jordan partial pivot' if algo_name == 'gj' else 'Cholesky'}"
+                             f" (C, OpenMP, schedule(dynamic,8))",
+           "host": {"model": cpu_model(), "logical_cpus": os.cpu_count(), "usable_cores": allc}}
+    if allc != 8:
+        v8, s8 = timed(min(8, allc))
+        out["omp8"] = {"value": v8, "cores": min(8, allc), "sample": s8}
+    return out
 
 
 def run_mixed(args, api, device, rank, world):
@@ -199,16 +222,31 @@ def rooflines(algo_name, n, batch, kern_ms):
     return (hbm, mf) if hbm["frac"] >= mf["frac"] else (mf, hbm)
 
 
-def load_traffic(kernel_name, n):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
+def load_traffic(kernel_name, n, batch):
+    """HBM bytes of ONE launch of `batch` matrices, scaled from the bytes per matrix that the committed rocprofv3 --pmc passes
+    measured (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE in separate passes, corrected as the guide prescribes), or
+    (None, None). It is NOT measured in this run: the source is named in the JSON."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(p):
-        return None
     try:
         table = json.load(open(p))
+        d = table[f"{kernel_name}|n={n}|detail"]
+        per_matrix = (d["read_bytes"] + d["write_bytes"]) / d["batch"]
+        return per_matrix * batch, f"profiles/traffic.json ({d['source']}: {per_matrix:.0f} B per matrix x {batch})"
     except Exception:
-        return None
-    return table.get(f"{kernel_name}|n={n}")
+        return None, None
+
+
+XGMI_LINK_GBS = 153.6  # per link and direction, 7 links per GPU (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def time_launches(fn, reps):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s_, e_ in ev:
+        s_.record()
+        fn()
+        e_.record()
+    torch.cuda.synchronize()
+    return [s_.elapsed_time(e_) for s_, e_ in ev]
 
 
 def main():
@@ -217,10 +255,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="gj64", choices=sorted(WORKLOADS) + ["mixed"])
-    ap.add_argument("--batch", type=int, default=100_000, help="matrices per GPU per step")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "lds", "rowlane", "tile", "tilep", "row"])
+    ap.add_argument("--batch", type=int, default=None, help="matrices per GPU per step (default: 100 000 on one GPU; "
+                                                             "with --gpus N > 1 the shard of --total-batch)")
+    ap.add_argument("--total-batch", type=int, default=1_000_000, help="N > 1: matrices over ALL GPUs (BASELINE configs[3])")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "lds", "rowlane", "tile", "tilep", "row", "blocked"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other single-GPU workloads")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the timed all-gather of the results")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -247,6 +288,7 @@ def main():
     coll_dev = device if backend == "nccl" else torch.device("cpu")
 
     api = importlib.import_module(PKG + ".api")
+    shard = importlib.import_module(PKG + ".shard")
     if args.workload == "mixed":
         run_mixed(args, api, device, rank, world)
         if dist is not None:
@@ -255,21 +297,39 @@ def main():
     n, algo_name, desc = WORKLOADS[args.workload]
     algo = api.ALGO_GAUSS_JORDAN if algo_name == "gj" else api.ALGO_CHOLESKY
     kernel = {"auto": api.KERNEL_AUTO, "lds": api.KERNEL_LDS, "rowlane": api.KERNEL_ROWLANE,
-              "tile": api.KERNEL_TILE, "tilep": api.KERNEL_TILEP, "row": api.KERNEL_ROW}[args.kernel]
-    batch = args.batch
+              "tile": api.KERNEL_TILE, "tilep": api.KERNEL_TILEP, "row": api.KERNEL_ROW, "blocked": api.KERNEL_BLOCKED}[args.kernel]
+    # which matrices are mine
+    if args.batch is not None or world == 1:
+        batch = args.batch if args.batch is not None else 100_000
+        total_batch, lo, scaling = batch * world, rank * batch, "weak"
+        sharding = f"{batch} matrices per GPU x {world} GPU(s), no data-path collective"
+    else:
+        total_batch = args.total_batch
+        parts = shard.partition(total_batch, world, shard.packing_multiple(n))
+        lo, hi = parts[rank]
+        batch, scaling = hi - lo, "strong"
+        sharding = (f"total batch {total_batch} block-partitioned over {world} GPUs by shard.partition "
+                    f"(rank 0: {parts[0][1] - parts[0][0]} matrices), each rank generates its shard from seed 0x5EED + rank; "
+                    f"no data-path collective")
 
     general = args.workload in GENERAL
     a = (make_general if general else make_spd)(n, batch, 0x5EED + rank, device)
     x = torch.empty_like(a)
-    info = torch.empty(batch, dtype=torch.int32, device=device)
+    info = torch.empty(max(batch, 1), dtype=torch.int32, device=device)
 
     def step():
         api.inverse_batched(a, n, algo, out=x, info=info, kernel=kernel, batch=batch)
 
+    # what a plain device-to-device copy of the same bytes reaches on this box (SURVEY 8d asks for the fraction against
+    # the measured copy bandwidth beside the nominal 8 TB/s); torch's copy kernel, same read+write byte count. Measured
+    # before the timed region: it belongs to the set-up, and the card has then left its idle clocks when the steps start
+    x.copy_(a)
+    copy_gbs = 2 * a.numel() * a.element_size() / (float(np.median(time_launches(lambda: x.copy_(a), 9))) * 1e-3) / 1e9
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    assert int(info.abs().sum()) == 0, "synthetic SPD batch reported singular matrices"
+    assert int(info[:batch].abs().sum()) == 0, "synthetic batch reported singular matrices"
 
     # HIP events on the stream the kernel is launched on (api passes torch's current stream to the C ABI)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -287,21 +347,35 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
 
-    gather_ms = None
+    gather = None
     if dist is not None:
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0].item()), float(t[1].item())
-        shard = importlib.import_module(PKG + ".shard")
-        torch.cuda.synchronize()
-        dist.barrier()
-        g0 = time.perf_counter()
-        # result reassembly on every rank (RCCL all-gather over xGMI); host staging only in the gloo rehearsal
-        full = shard.all_gather_shards(x if backend == "nccl" else x.cpu(), n, batch * world)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        assert full.numel() == batch * world * n * n
-        del full
+        ones = torch.ones(1, dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(ones)  # through the data-path backend (RCCL): how many ranks really took part
+        ranks_seen = int(ones.item())
+        if not args.no_gather:
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = time.perf_counter()
+            # result reassembly on every rank (ONE RCCL all-gather over xGMI); host staging only in the gloo rehearsal
+            full = shard.all_gather_shards(x if backend == "nccl" else x.cpu(), n, total_batch)
+            torch.cuda.synchronize()
+            gms = (time.perf_counter() - g0) * 1e3
+            assert full.numel() == total_batch * n * n
+            recv = (total_batch - batch) * n * n * x.element_size()  # bytes this rank received from the others
+            tg = torch.tensor([gms], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            gms = float(tg.item())
+            gather = {"allgather_ms": gms, "allgather_GBs_per_rank_in": recv / (gms * 1e-3) / 1e9,
+                      "gathered_bytes_per_rank": total_batch * n * n * x.element_size(),
+                      "xgmi_bound_GBs_per_rank_in": XGMI_LINK_GBS * min(world - 1, 7),
+                      "xgmi_per_link_GBs": XGMI_LINK_GBS, "backend": backend}
+            del full
+        else:
+            gather = {"backend": backend}
+        gather["n_ranks_seen"] = ranks_seen
 
     # quick correctness guard on the timed output (not timed): residual of a few matrices
     am = a.view(batch, n, n)[:8]
@@ -309,51 +383,42 @@ def main():
     resid = float((torch.bmm(am, xm) - torch.eye(n, dtype=a.dtype, device=device)).abs().max())
     assert resid < (1e-9 if general else 1e-11) * n, f"residual {resid}"
 
-    # what a plain device-to-device copy of the same bytes reaches on this box (SURVEY 8d asks for the fraction against
-    # the measured copy bandwidth beside the nominal 8 TB/s); torch's copy kernel, same read+write byte count
-    copy_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-    x.copy_(a)
-    for s_, e_ in copy_ev:
-        s_.record()
-        x.copy_(a)
-        e_.record()
-    torch.cuda.synchronize()
-    copy_gbs = 2 * a.numel() * a.element_size() / (float(np.median([s_.elapsed_time(e_) for s_, e_ in copy_ev])) * 1e-3) / 1e9
-
     others = {}
     if rank == 0 and world == 1 and not args.no_others:
-        # the other single-GPU configs of BASELINE.json, a few launches each (same timing method), for the record
+        # the other single-GPU workloads, a few launches each (same timing method), so that every path -- the weak ones
+        # included -- is driver-timed each round
         del a, x
-        for wname in ("gj16", "chol64", "gj32", "gj8", "gj128"):
+        for wname in ("gj16", "chol64", "gj32", "gj8", "gj128", "gj64g", "gj32g", "gj128g", "gj256g", "chol256"):
             if wname == args.workload:
                 continue
             n2, algo2_name, _ = WORKLOADS[wname]
             algo2 = api.ALGO_GAUSS_JORDAN if algo2_name == "gj" else api.ALGO_CHOLESKY
-            b2 = min(batch, 25_000) if n2 >= 128 else batch
-            a2 = make_spd(n2, b2, 0x5EED + 17 * n2, device)
+            b2 = 100_000 if n2 <= 64 else (25_000 if n2 <= 128 else 3_000)
+            a2 = (make_general if wname in GENERAL else make_spd)(n2, b2, 0x5EED + 17 * n2, device)
             x2 = torch.empty_like(a2)
-            for _ in range(2):
-                api.inverse_batched(a2, n2, algo2, out=x2, batch=b2)
-            ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-            for s_, e_ in ev2:
-                s_.record()
-                api.inverse_batched(a2, n2, algo2, out=x2, batch=b2)
-                e_.record()
-            torch.cuda.synchronize()
-            ms2 = float(np.mean([s_.elapsed_time(e_) for s_, e_ in ev2]))
+            i2 = torch.empty(b2, dtype=torch.int32, device=device)
+            for _ in range(3):  # the adaptive dispatch of the tile family settles on the second launch
+                api.inverse_batched(a2, n2, algo2, out=x2, info=i2, batch=b2)
+            ms2 = float(np.mean(time_launches(lambda: api.inverse_batched(a2, n2, algo2, out=x2, batch=b2), 5)))
             r1, r2 = rooflines(algo2_name, n2, b2, ms2)
-            others[wname] = {"kernel": api.kernel_name(algo2, api.F64, n2), "batch": b2, "kernel_ms": ms2,
+            kname2 = api.kernel_name(algo2, api.F64, n2)
+            if wname in GENERAL and n2 <= 64:
+                kname2 = api.kernel_name(algo2, api.F64, n2, api.KERNEL_TILEP)
+            others[wname] = {"kernel": kname2, "batch": b2, "kernel_ms": ms2, "input": "general U(0,1)" if wname in GENERAL else "SPD",
                              "inversions_per_s": b2 / (ms2 * 1e-3), "bound": r1["bound"], "frac": r1["frac"],
                              "achieved": r1["achieved"], "unit": r1["unit"],
-                             "other_bound_frac": None if r2 is None else r2["frac"]}
+                             "other_bound_frac": None if r2 is None else r2["frac"], "singular_reported": int((i2 != 0).sum())}
             del a2, x2
 
     if rank == 0:
-        total = batch * world * args.steps
-        value = total / elapsed
+        value = total_batch * args.steps / elapsed
         kname = api.kernel_name(algo, api.F64, n, kernel)
+        if general and n <= 64 and kernel == api.KERNEL_AUTO:
+            kname = api.kernel_name(algo, api.F64, n, api.KERNEL_TILEP)  # where the adaptive dispatch sends a general batch
         roof, roof_other = rooflines(algo_name, n, batch, kern_ms)
-        roof.update({"traffic": load_traffic(kname, n), "kernel": kname, "kernel_ms": kern_ms})
+        traffic, traffic_src = load_traffic(kname, n, batch)
+        roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "kernel_ms": kern_ms,
+                     "units_per_launch": batch, "per": "GPU"})
         hbm_side = roof if roof["bound"] == "hbm" else roof_other
         hbm_side["measured_copy_GBs"] = copy_gbs
         hbm_side["frac_of_measured_copy"] = hbm_side["achieved"] / copy_gbs
@@ -362,14 +427,16 @@ def main():
         out = {
             "metric": "matrix inversions/s", "value": value, "unit": "inversions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc.replace('batch', str(batch))}", "n": n,
-                       "batch_per_gpu": batch, "algorithm": algo_name, "kernel": kname,
-                       "sharding": f"batch block-partitioned over {world} GPU(s), no data-path collective"},
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc.replace('batch', str(total_batch))}", "n": n,
+                       "total_batch": total_batch, "batch_per_gpu": batch, "algorithm": algo_name, "kernel": kname,
+                       "input": "general U(0,1)" if general else "SPD: R + R^T + n I", "sharding": sharding},
             "roofline": roof,
         }
-        if gather_ms is not None:
-            out["allgather_ms"] = gather_ms
+        if gather is not None:
+            out["gather"] = gather
+            if "allgather_ms" in gather:
+                out["allgather_ms"] = gather["allgather_ms"]
         if others:
             out["other_workloads"] = others
         if not args.no_cpu_baseline and world == 1:

@@ -153,16 +153,17 @@ template <>
 hipError_t launch_gj_tilep<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
 template <>
 hipError_t launch_gj_tilep<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
-// work-list form: inverts in_list[0 .. *in_count) (device memory); scratch = batch + 1 ints for the singular ones
+// work-list form: inverts in_list[0 .. *in_count) (device memory); singular ones go on to the ROW kernel through
+// (bad_count, bad_list), zeroed by the caller; hint_out (pinned host memory, may be null) receives the list length
 template <class T>
 hipError_t launch_gj_tilep_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count, const int *in_list,
-                                    int *scratch, int *info, hipStream_t stream);
+                                    int *bad_count, int *bad_list, int *info, hipStream_t stream, int *hint_out);
 template <>
 hipError_t launch_gj_tilep_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
-                                            const int *in_list, int *scratch, int *info, hipStream_t stream);
+                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, int *hint_out);
 template <>
 hipError_t launch_gj_tilep_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
-                                           const int *in_list, int *scratch, int *info, hipStream_t stream);
+                                           const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, int *hint_out);
 const char *name_gj_tilep(bool f64, int n);
 // Adaptive choice between the natural-order (verified) tile kernel and the pivoting one (tile_kernels.hip): see gj_tile_policy
 struct TileStats {
@@ -170,7 +171,7 @@ struct TileStats {
 };
 TileStats tile_stats();
 bool tile_policy_use_pivot(bool f64, int nt);
-void tile_policy_record(bool f64, int nt, const int *dev_count, size_t batch, hipStream_t stream);
+int *tile_policy_record(bool f64, int nt, size_t batch);
 
 const char *name_gj_rowlane(bool f64, int n);
 const char *name_gj_tile(bool f64, int n);

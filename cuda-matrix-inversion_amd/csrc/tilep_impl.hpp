@@ -19,9 +19,9 @@
 //     slot (tile row, register) lets the one lane group that holds it store the row and zero it in C. That switch is the
 //     only place where a run-time register index is needed, and it is why the block-step loop is unrolled over the tile
 //     column only (the register index of the pivot COLUMNS) and rolled over the four blocks inside it.
-// Cost per block step at n = 64: ~45 more VALU instructions than the verified-natural-order kernel and three LDS round
-// trips instead of one; no acceptance test, no work list except for singular input (no finite non-zero pivot candidate),
-// which goes to the ROW kernel for its exact info code.
+// Cost per block step at n = 64: ~45 more VALU instructions than the verified-natural-order kernel and two LDS round
+// trips instead of one; no acceptance test; a work list only for singular input (no finite non-zero pivot candidate in
+// some column), which the ROW kernel redoes for the oracle's info code (this kernel eliminates A^T).
 //
 // Replaces pivotRow / normalizeRow / transform_matrix of /root/reference/src/gauss/batched_invert.cu:17-82 for inputs that
 // need row exchanges (the reference swaps only on an exactly zero diagonal, :19-35; tests/square_5_*.mats are such inputs).
@@ -152,8 +152,8 @@ struct IntC {
 
 template <class T, int NT, bool FULL>
 __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
-                                              int *work_count, int *work_list, T *lds, unsigned char *tab,
-                                              const int *in_count = nullptr, const int *in_list = nullptr)
+                                              T *lds, unsigned char *tab, const int *in_count, const int *in_list, int *hint_out,
+                                              int *bad_count, int *bad_list)
 {
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
@@ -168,6 +168,9 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
 
     // work-list form (the matrices the natural-order kernel rejected): in_list[0 .. *in_count)
     const unsigned todo = in_count ? (unsigned)*in_count : batch;
+    // work-list form: the length of the list is what the launcher's natural-order / pivot guess feeds on; it goes back to
+    // the host through a store into pinned memory (no copy command in the stream, nobody waits for it)
+    if (hint_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint_out, (int)todo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (unsigned item = blockIdx.x; item < todo; item += gridDim.x) {
         const unsigned mat = in_list ? (unsigned)in_list[item] : item;
         const T *A = Ain.at_uniform(mat);
@@ -252,7 +255,7 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
                     // largest |w_t| over the rows not used yet; lowest row slot on ties
                     const unsigned key = used ? 0u : magkey(w[t]);
                     const unsigned mx = wave_max_u32(key);
-                    if (key_bad(T(0), mx) && bad == 0) bad = 1;
+                    if (key_bad(T(0), mx)) bad = 1;  // no usable pivot in this column: singular (or NaN / Inf in the input)
                     // key == mx != 0 implies a candidate row (the others carry key 0; mx == 0 is the singular case)
                     const unsigned long long vote = __builtin_amdgcn_uicmp(key, mx, 32 /* ICMP_EQ */);
                     p = vote ? (int)__builtin_ctzll(vote) : 0;
@@ -385,8 +388,10 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
                 }
             if (info && l == 0) info[mat] = 0;
         } else if (l == 0) {
-            const int slot = atomicAdd(work_count, 1);
-            work_list[slot] = (int)mat;
+            // singular: this kernel eliminates W = A^T, so the column at which IT runs out of pivots is not the oracle's
+            // (row pivoting on A). The ROW kernel redoes the matrix for the exact info code and the NaN fill.
+            const int slot = atomicAdd(bad_count, 1);
+            bad_list[slot] = (int)mat;
         }
         wave_lds_sync();
     }
@@ -394,46 +399,46 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
 
 template <int NT, bool FULL>
 __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
-                                                            unsigned batch, int *work_count, int *work_list,
-                                                            const int *in_count, const int *in_list)
+                                                            unsigned batch, const int *in_count, const int *in_list, int *hint_out,
+                                                            int *bad_count, int *bad_list)
 {
     __shared__ __attribute__((aligned(16))) double lds[256 + 4 * 16 * NT];
     __shared__ unsigned char tab[128];
-    gj_tilep_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab, in_count, in_list);
+    gj_tilep_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, lds, tab, in_count, in_list, hint_out, bad_count, bad_list);
 }
 
 template <int NT, bool FULL>
 __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n_rt,
-                                                            unsigned batch, int *work_count, int *work_list,
-                                                            const int *in_count, const int *in_list)
+                                                            unsigned batch, const int *in_count, const int *in_list, int *hint_out,
+                                                            int *bad_count, int *bad_list)
 {
     __shared__ __attribute__((aligned(16))) float lds[256 + 4 * 16 * NT];
     __shared__ unsigned char tab[128];
-    gj_tilep_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, work_count, work_list, lds, tab, in_count, in_list);
+    gj_tilep_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, lds, tab, in_count, in_list, hint_out, bad_count, bad_list);
 }
 
-// Enqueue the kernel only. in_count / in_list != nullptr: work-list form (grid sized for the worst case, blocks beyond
-// the list exit at once). Singular matrices are appended to (out_count, out_list).
+// in_count / in_list != nullptr: work-list form (one round of resident workgroups strides over the list; usually empty).
+// Singular matrices are appended to (bad_count, bad_list) for the ROW kernel.
 template <class T>
 static hipError_t enqueue_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
-                                int *out_count, int *out_list, const int *in_count, const int *in_list)
+                                const int *in_count, const int *in_list, int *hint_out, int *bad_count, int *bad_list)
 {
     const int nt = (n + 15) / 16;
     unsigned cap = 256u * 12u * tile_grid_rounds();
-    if (in_list && cap > 256u * 12u * 4u) cap = 256u * 12u * 4u;
+    if (in_list) cap = 256u * 12u;
     const unsigned grid = (unsigned)(batch < cap ? batch : cap);
     const unsigned b = (unsigned)batch;
 #define TP_LAUNCH(NT_)                                                                                                 \
     if constexpr (sizeof(T) == 8) {                                                                                    \
         if (n == 16 * NT_)                                                                                             \
-            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, out_count, out_list, in_count, in_list); \
+            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, in_count, in_list, hint_out, bad_count, bad_list); \
         else                                                                                                           \
-            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, out_count, out_list, in_count, in_list); \
+            hipLaunchKernelGGL((matinv_gj_tilep_f64<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, in_count, in_list, hint_out, bad_count, bad_list); \
     } else {                                                                                                           \
         if (n == 16 * NT_)                                                                                             \
-            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, out_count, out_list, in_count, in_list); \
+            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, true>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, in_count, in_list, hint_out, bad_count, bad_list); \
         else                                                                                                           \
-            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, out_count, out_list, in_count, in_list); \
+            hipLaunchKernelGGL((matinv_gj_tilep_f32<NT_, false>), dim3(grid), dim3(64), 0, stream, A, X, info, n, b, in_count, in_list, hint_out, bad_count, bad_list); \
     }
     switch (nt) {
     case 1: TP_LAUNCH(1) break;
@@ -458,23 +463,21 @@ static hipError_t launch_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t
         (void)hipFreeAsync(ws, stream);
         return e;
     }
-    e = enqueue_tilep<T>(n, A, X, batch, info, stream, ws, ws + 1, nullptr, nullptr);
-    // singular input only: the ROW kernel reports the exact step and NaN-fills the output
+    e = enqueue_tilep<T>(n, A, X, batch, info, stream, nullptr, nullptr, nullptr, ws, ws + 1);
     if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 
-// the rejected matrices of the natural-order kernel (in_count, in_list), then the singular ones among them on the ROW kernel;
-// scratch = batch + 1 ints for the second list
+// the matrices the natural-order kernel rejected: (in_count, in_list) in device memory; the singular ones among them go on
+// to the ROW kernel through (bad_count, bad_list), which the caller has zeroed
 template <class T>
 static hipError_t launch_tilep_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count,
-                                        const int *in_list, int *scratch, int *info, hipStream_t stream)
+                                        const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
+                                        int *hint_out)
 {
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int), stream);
-    if (e != hipSuccess) return e;
-    e = enqueue_tilep<T>(n, A, X, batch, info, stream, scratch, scratch + 1, in_count, in_list);
-    if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, scratch, scratch + 1, info, stream);
+    hipError_t e = enqueue_tilep<T>(n, A, X, batch, info, stream, in_count, in_list, hint_out, bad_count, bad_list);
+    if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, bad_count, bad_list, info, stream);
     return e;
 }
 

@@ -1,0 +1,50 @@
+"""Worker of tests/test_gpu_multirank.py: launched by torch.distributed.run with 2 ranks that SHARE cuda:0 (gloo for the
+collective). Each rank inverts its shard with the HIP kernels through the C ABI, the shards are all-gathered, and every
+rank checks the result bit for bit against ONE launch over the whole batch."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import general_batch, spd_batch  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    api = importlib.import_module("cuda-matrix-inversion_amd.api")
+    shard = importlib.import_module("cuda-matrix-inversion_amd.shard")
+    ok = True
+    for n, batch, algo, gen in ((8, 1003, 0, spd_batch), (16, 1001, 0, spd_batch), (64, 300, 0, spd_batch),
+                                (64, 300, 1, spd_batch), (64, 257, 0, general_batch), (128, 41, 0, spd_batch),
+                                (200, 9, 0, general_batch)):
+        a = gen(n, batch, seed=100 + n)
+        lo, hi = shard.partition(batch, world, shard.packing_multiple(n))[rank]
+        mine = torch.from_numpy(a[lo * n * n: hi * n * n]).cuda()
+        for _ in range(2):  # twice: the adaptive dispatch may take the other kernel the second time -- same bits required
+            local = api.inverse_batched(mine, n, algo, batch=hi - lo) if hi > lo else mine
+            torch.cuda.synchronize()
+            full = shard.all_gather_shards(local.cpu(), n, batch)
+            whole = api.inverse_batched(torch.from_numpy(a).cuda(), n, algo, batch=batch)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(full, whole.cpu()))
+            ok = ok and same
+            if not same:
+                print(f"rank {rank}: n={n} batch={batch} algo={algo} MISMATCH", flush=True)
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print("TWO_RANK_OK" if int(flag) == 1 else "TWO_RANK_FAIL", flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()
