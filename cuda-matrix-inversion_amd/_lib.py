@@ -34,7 +34,8 @@ NATIVE_NAMES = [
     "matinv_mean_batched", "matinv_variance_batched", "matinv_inverse_batched_host", "matinv_mean_batched_host",
     "matinv_variance_batched_host", "matinv_last_error",
     "matinv_abi_version", "matinv_release_cache", "matinv_batched_malloc", "matinv_batched_free", "matinv_memcpy_2d",
-    "matinv_device_synchronize", "matinv_tile_stats",
+    "matinv_device_synchronize", "matinv_tile_stats", "matinv_queue_create", "matinv_queue_submit", "matinv_queue_submit_chunks", "matinv_queue_pending",
+    "matinv_queue_bins", "matinv_queue_flush", "matinv_queue_destroy", "matinv_queue_last_error",
 ]
 
 
@@ -90,6 +91,22 @@ def lib() -> ctypes.CDLL:
     L.matinv_memcpy_2d.restype = ci
     L.matinv_memcpy_2d.argtypes = [vp, sz, vp, sz, sz, sz, ci]
     L.matinv_device_synchronize.restype = ci
+    L.matinv_queue_create.restype = ci
+    L.matinv_queue_create.argtypes = [vp, ci, vp, ci]
+    L.matinv_queue_submit.restype = ci
+    L.matinv_queue_submit.argtypes = [vp, ci, vp, vp, vp, vp, vp, sz, vp]
+    L.matinv_queue_submit_chunks.restype = ci
+    L.matinv_queue_submit_chunks.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.matinv_queue_pending.restype = ci
+    L.matinv_queue_pending.argtypes = [vp, vp, vp]
+    L.matinv_queue_bins.restype = ci
+    L.matinv_queue_bins.argtypes = [vp, vp, ci]
+    L.matinv_queue_flush.restype = ci
+    L.matinv_queue_flush.argtypes = [vp, vp, vp, vp]
+    L.matinv_queue_destroy.restype = ci
+    L.matinv_queue_destroy.argtypes = [vp]
+    L.matinv_queue_last_error.restype = ctypes.c_char_p
+    L.matinv_queue_last_error.argtypes = [vp]
     L.matinv_last_error.restype = ctypes.c_char_p
     L.matinv_abi_version.restype = ci
     L.matinv_release_cache.restype = ci

@@ -1,19 +1,20 @@
-"""Size-binned multi-queue for mixed-size Gaussian-process items.
+"""Size-binned multi-queue for mixed-size Gaussian-process items: thin mirror of the C queue of libmatinv_hip.so.
 
 The reference only sketches this ("use multiple queues for different sizes: 32, 128, 512, 1024",
-/root/reference/README.md:41-44) and never built it; BASELINE.json configs[4] asks for it. Items (a, B, c, d[, e]) of
-arbitrary n are appended to the queue of the smallest bin that holds them; `flush()` turns every non-empty queue into
-device-resident batches -- one per padded size, see SizeBinnedQueue; padding is an identity block in B and zeros in the
-vectors, which leaves a^T (B + diag c)^-1 d unchanged -- and launches the fused pipeline kernel on the bin's own HIP
-stream, so the bins overlap on the device. Results come back in submission order.
+/root/reference/README.md:41-44) and never built it; BASELINE.json configs[4] asks for it. The queue itself --
+binning, grouping by exact n, run detection, the segmented gather, one stream per bin -- is C behind the C ABI
+(csrc/queue.hip: matinv_queue_create / submit / flush, include/matinv.h); this module only keeps the submitted torch
+tensors alive until the flush and hands their device pointers over. Results come back in submission (ticket) order.
 
-torch supplies device memory and streams; all arithmetic is libmatinv_hip.so (api.calcluateMean / calcluateVariance).
 Across GPUs the item list is dealt out by `shard_items` (largest first, round-robin) with no communication; rank results
 are small (one scalar per item) and can be gathered with torch.distributed.all_gather_object by the caller.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import List, Optional, Sequence, Tuple
+
+from . import _lib
 
 DEFAULT_BINS = (32, 128, 512, 1024)
 
@@ -34,41 +35,54 @@ def shard_items(sizes: Sequence[int], rank: int, world: int) -> List[int]:
 
 
 def pad_item(a, B, c, d, n: int, nb: int):
-    """Embed an n-item into an nb-item: B -> blockdiag(B, I), vectors zero-extended. B is n*n column-major flat or (n, n)."""
-    return pad_items(a, B, c, d, n, nb, 1)
-
-
-def pad_items(a, B, c, d, n: int, nb: int, count: int):
-    """`count` equally sized n-items (flat, item-major) embedded into nb-items in one shot."""
+    """Embed an n-item into an nb-item: B -> blockdiag(B, I), vectors zero-extended (the scalar a^T (B + diag c)^-1 d does not
+    change). The queue no longer needs it -- the kernels pad in registers -- it documents the identity the kernels rely on."""
     import torch
     if n == nb:
         return a.reshape(-1), B.reshape(-1), c.reshape(-1), d.reshape(-1)
-    Bp = torch.eye(nb, dtype=B.dtype, device=B.device).repeat(count, 1, 1)
-    Bp[:, :n, :n] = B.reshape(count, n, n)
+    Bp = torch.eye(nb, dtype=B.dtype, device=B.device)
+    Bp[:n, :n] = B.reshape(n, n)
 
     def z(v):
-        out = torch.zeros((count, nb), dtype=v.dtype, device=v.device)
-        out[:, :n] = v.reshape(count, n)
-        return out.reshape(-1)
+        out = torch.zeros(nb, dtype=v.dtype, device=v.device)
+        out[:n] = v.reshape(n)
+        return out
     return z(a), Bp.reshape(-1), z(c), z(d)
 
 
 class SizeBinnedQueue:
-    """`pad_to="tile"` (default): inside a bin, items are grouped by n rounded up to a multiple of 16 (never beyond the bin) and
-    each group is one launch at that size -- the kernels serve any n, so an n = 40 item in the 128 bin costs what a 48 x 48
-    item costs, not what a 128 x 128 one does. `pad_to="bin"`: the reference sketch's literal policy, everything padded to
-    the bin size, one launch per bin."""
+    """matinv_queue_* over torch CUDA tensors. One queue serves one dtype (fixed by the first item)."""
 
-    def __init__(self, bins: Sequence[int] = DEFAULT_BINS, device=None, pad_to: str = "tile"):
+    def __init__(self, bins: Sequence[int] = DEFAULT_BINS, device=None):
         import torch
-        if pad_to not in ("tile", "bin"):
-            raise ValueError("pad_to must be 'tile' or 'bin'")
-        self.pad_to = pad_to
         self.bins = tuple(sorted(bins))
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self._queues = {b: [] for b in self.bins}   # bin -> list of chunks (first ticket, count, n, a, B, c, d, e)
-        self._streams = {b: torch.cuda.Stream(device=self.device) for b in self.bins}
+        self._q = None
+        self._dtype = None
+        self._keep = []   # tensors of the pending chunks (the C queue holds raw pointers)
         self._tickets = 0
+        self._want_var = True
+
+    def _handle(self, dtype):
+        import torch
+        if self._q is None:
+            self._dtype = dtype
+            q = ctypes.c_void_p()
+            arr = (ctypes.c_int * len(self.bins))(*self.bins)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().matinv_queue_create(ctypes.byref(q), _lib.F64 if dtype == torch.float64 else _lib.F32,
+                                                          arr, len(self.bins)))
+            self._q = q
+        elif dtype != self._dtype:
+            raise TypeError("one queue serves one dtype")
+        return self._q
+
+    def __del__(self):
+        try:
+            if self._q is not None:
+                _lib.lib().matinv_queue_destroy(self._q)
+        except Exception:
+            pass
 
     def submit(self, a, B, c, d, e=None) -> int:
         """Queue one item; tensors are CUDA tensors of one dtype. Returns its ticket (position in the result)."""
@@ -82,54 +96,82 @@ class SizeBinnedQueue:
         if As.numel() != count * n or Bs.numel() != count * n * n or Cs.numel() != count * n or Ds.numel() != count * n \
                 or (Es is not None and Es.numel() != count):
             raise ValueError("inconsistent item shapes")
-        t = self._tickets
+        ts = [t if t.is_contiguous() else t.contiguous() for t in (As, Bs, Cs, Ds)] + ([Es.contiguous()] if Es is not None else [])
+        if any(not t.is_cuda or t.dtype != As.dtype for t in ts):
+            raise ValueError("items must be CUDA tensors of one dtype")
+        q = self._handle(As.dtype)
+        bin_of(n, self.bins)  # raises for n beyond the largest bin, like the C side
+        first = ctypes.c_size_t()
+        p = [t.data_ptr() for t in ts] + ([None] if Es is None else [])
+        rc = _lib.lib().matinv_queue_submit(q, int(n), p[0], p[1], p[2], p[3], p[4], int(count), ctypes.byref(first))
+        if rc != _lib.OK:
+            raise _lib.MatinvError(rc, _lib.lib().matinv_queue_last_error(q).decode())
+        self._keep.append(ts)
         self._tickets += count
-        self._queues[bin_of(n, self.bins)].append((t, count, n, As, Bs, Cs, Ds, Es))
-        return t
+        self._want_var = self._want_var and Es is not None
+        return int(first.value)
+
+    def chunk_table(self, chunks):
+        """Prepare a list of chunks [(n, As, Bs, Cs, Ds[, Es]), ...] for `submit_table`: the pointer arrays the C call takes
+        (matinv_queue_submit_chunks). The tensors are kept alive by the table."""
+        import torch
+        k = len(chunks)
+        with_e = all(len(ch) > 5 and ch[5] is not None for ch in chunks)
+        ts = [[t.contiguous() for t in ch[1:5]] + ([ch[5].contiguous()] if with_e else []) for ch in chunks]
+        dtype = ts[0][0].dtype
+        if any(not t.is_cuda or t.dtype != dtype for row in ts for t in row):
+            raise ValueError("items must be CUDA tensors of one dtype")
+        ns = [int(ch[0]) for ch in chunks]
+        counts = [row[0].numel() // n for row, n in zip(ts, ns)]
+        for row, n, cnt in zip(ts, ns, counts):
+            bin_of(n, self.bins)
+            if row[0].numel() != cnt * n or row[1].numel() != cnt * n * n or row[2].numel() != cnt * n or row[3].numel() != cnt * n \
+                    or (with_e and row[4].numel() != cnt):
+                raise ValueError("inconsistent item shapes")
+        arr = lambda j: (ctypes.c_void_p * k)(*[row[j].data_ptr() for row in ts])
+        return {"k": k, "n": (ctypes.c_int * k)(*ns), "count": (ctypes.c_size_t * k)(*counts), "ptr": [arr(j) for j in range(4)],
+                "e": arr(4) if with_e else None, "tickets": (ctypes.c_size_t * k)(), "keep": ts, "dtype": dtype, "items": sum(counts)}
+
+    def submit_table(self, table):
+        """Queue every chunk of a prepared table with ONE C call; returns the first tickets of the chunks."""
+        q = self._handle(table["dtype"])
+        rc = _lib.lib().matinv_queue_submit_chunks(q, table["k"], table["n"], *table["ptr"], table["e"], table["count"], table["tickets"])
+        if rc != _lib.OK:
+            raise _lib.MatinvError(rc, _lib.lib().matinv_queue_last_error(q).decode())
+        self._keep.append([t for row in table["keep"] for t in row])
+        self._tickets += table["items"]
+        self._want_var = self._want_var and table["e"] is not None
+        return list(table["tickets"])
 
     def pending(self):
-        return {b: sum(ch[1] for ch in q) for b, q in self._queues.items() if q}
+        if self._q is None:
+            return {}
+        per = (ctypes.c_size_t * len(self.bins))()
+        _lib.check(_lib.lib().matinv_queue_pending(self._q, None, per))
+        return {b: int(v) for b, v in zip(self.bins, per) if v}
 
     def flush(self) -> Tuple["torch.Tensor", Optional["torch.Tensor"]]:
-        """Run every bin; returns (means, variances or None) in ticket order and empties the queues."""
+        """Run every bin; returns (means, variances or None) in ticket order and empties the queue. Variances are computed
+        when every pending item carried an e. Asynchronous on torch's current stream."""
         import torch
-        from . import api
         total = self._tickets
         if total == 0:
             return torch.empty(0, device=self.device), None
-        first = next(q[0] for q in self._queues.values() if q)
-        dtype = first[3].dtype
-        means = torch.empty(total, dtype=dtype, device=self.device)
-        want_var = any(ch[7] is not None for q in self._queues.values() for ch in q)
-        variances = torch.empty(total, dtype=dtype, device=self.device) if want_var else None
-        cur = torch.cuda.current_stream(self.device)
-        for b in sorted(self._queues, reverse=True):  # largest bin first: its many small launches overlap the rest
-            q = self._queues[b]
-            if not q:
-                continue
-            s = self._streams[b]
-            s.wait_stream(cur)  # the items were produced on the caller's stream
-            with torch.cuda.stream(s):
-                groups = {}
-                for ch in q:
-                    pn = b if self.pad_to == "bin" else min(b, -(-ch[2] // 16) * 16)
-                    groups.setdefault(pn, []).append(ch)
-                for pn in sorted(groups, reverse=True):
-                    g = groups[pn]
-                    padded = [pad_items(a, B, c, d, n, pn, cnt) for (_, cnt, n, a, B, c, d, _) in g]
-                    A_, B_, C_, D_ = (torch.cat([p[k] for p in padded]).contiguous() for k in range(4))
-                    nitems = sum(ch[1] for ch in g)
-                    idx = torch.cat([torch.arange(t, t + cnt, device=self.device) for (t, cnt, *_rest) in g]) \
-                        if len(g) < 64 else torch.tensor([t + i for (t, cnt, *_rest) in g for i in range(cnt)], device=self.device)
-                    out = api.calcluateMean(pn, A_, B_, C_, D_, batchSize=nitems)
-                    means.index_copy_(0, idx, out)
-                    if want_var:
-                        E_ = torch.cat([(ch[7].reshape(-1) if ch[7] is not None
-                                         else torch.zeros(ch[1], dtype=dtype, device=self.device)) for ch in g])
-                        var = api.calcluateVariance(pn, A_, B_, C_, E_, batchSize=nitems)
-                        variances.index_copy_(0, idx, var)
-        for s in self._streams.values():
-            cur.wait_stream(s)
-        self._queues = {b: [] for b in self.bins}
+        means = torch.empty(total, dtype=self._dtype, device=self.device)
+        variances = torch.empty(total, dtype=self._dtype, device=self.device) if self._want_var else None
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().matinv_queue_flush(self._q, ctypes.c_void_p(means.data_ptr()),
+                                               ctypes.c_void_p(variances.data_ptr()) if variances is not None else None,
+                                               ctypes.c_void_p(stream.cuda_stream))
+        if rc != _lib.OK:
+            raise _lib.MatinvError(rc, _lib.lib().matinv_queue_last_error(self._q).decode())
+        # the chunks must outlive the asynchronous launches: their memory is returned to torch's caching allocator only
+        # after the current stream has passed this point
+        for ts in self._keep:
+            for t in ts:
+                t.record_stream(stream)
+        self._keep = []
         self._tickets = 0
+        self._want_var = True
         return means, variances

@@ -132,6 +132,29 @@ int matinv_device_synchronize(void);
 int matinv_tile_stats(unsigned long long *natural_launches, unsigned long long *pivot_launches, unsigned long long *last_rejected,
                       unsigned long long *last_batch);
 
+/* Size-binned multi-queue for mixed-size pipeline items (the reference sketches it, README.md:41-44: "use multiple queues
+ * for different sizes: 32, 128, 512, 1024"; BASELINE configs[4]). Items of any n <= the largest bin are submitted as
+ * chunks of `count` equally sized items lying back to back in device memory (As, Cs, Ds: count*n; Bs: count*n*n
+ * column-major; Es: count scalars or NULL); submit only records the chunk and hands out consecutive tickets. flush runs
+ * every bin on its own HIP stream (forked from and joined back into `stream`), one launch of the fused mean (and variance)
+ * kernel per distinct n of a bin -- the kernels pad a matrix to their tile size in registers, nothing is padded in memory --
+ * gathering a group's chunks with one segmented-copy kernel unless they already form one contiguous run, and writes
+ * means[ticket] (and variances[ticket] when dVariances != NULL, which needs every item to carry e). Asynchronous; the
+ * item memory must stay valid until the work in `stream` has completed. bins == NULL / nbins == 0: {32, 128, 512, 1024}. */
+typedef struct matinv_queue matinv_queue;
+int matinv_queue_create(matinv_queue **q, int dtype, const int *bins, int nbins);
+int matinv_queue_submit(matinv_queue *q, int n, const void *dAs, const void *dBs, const void *dCs, const void *dDs,
+                        const void *dEs, size_t count, size_t *first_ticket);
+/* the same for `chunks` chunks in one call (arrays of `chunks` entries; dEs NULL = no item carries e) */
+int matinv_queue_submit_chunks(matinv_queue *q, size_t chunks, const int *n, const void *const *dAs, const void *const *dBs,
+                               const void *const *dCs, const void *const *dDs, const void *const *dEs, const size_t *count,
+                               size_t *first_tickets);
+int matinv_queue_pending(const matinv_queue *q, size_t *items, size_t *per_bin);
+int matinv_queue_bins(const matinv_queue *q, int *bins, int cap);
+int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *stream);
+int matinv_queue_destroy(matinv_queue *q);
+const char *matinv_queue_last_error(const matinv_queue *q);
+
 const char *matinv_last_error(void);
 int matinv_abi_version(void);
 

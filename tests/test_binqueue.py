@@ -60,13 +60,14 @@ def test_mixed_size_stream_matches_oracle(dtype):
 
 
 @pytest.mark.gpu
-def test_padding_policies_agree():
-    """pad_to="tile" (groups by n rounded up to 16 inside a bin) and pad_to="bin" (the literal policy) give the same scalars."""
+def test_device_side_padding_agrees_with_explicit_padding():
+    """The queue never pads in memory (the kernels pad to their tile size in registers); an explicitly identity-padded copy
+    of an item -- the reference sketch's pad-to-the-bin policy -- gives the same scalar."""
     import torch
     bq = pkg("binqueue")
     rng = np.random.default_rng(9)
     sizes = [5, 17, 40, 100, 128, 33, 130, 300, 16, 64]
-    qa, qb = bq.SizeBinnedQueue(pad_to="tile"), bq.SizeBinnedQueue(pad_to="bin")
+    qa, qb = bq.SizeBinnedQueue(), bq.SizeBinnedQueue()
     want = []
     for i, n in enumerate(sizes):
         B = spd_batch(n, 1, seed=200 + i)
@@ -74,11 +75,12 @@ def test_padding_policies_agree():
         want.append(oracle.mean_batched(a, B, c, d, n)[0])
         t = [torch.from_numpy(x).cuda() for x in (a, B, c, d)]
         qa.submit(*t)
-        qb.submit(*t)
+        qb.submit(*bq.pad_item(*t, n, bq.bin_of(n)))
+    assert qa.pending() == qb.pending()
     ma, mb = qa.flush()[0].cpu().numpy(), qb.flush()[0].cpu().numpy()
     assert np.abs(ma - np.array(want)).max() < 1e-10 and np.abs(mb - np.array(want)).max() < 1e-10
     with pytest.raises(ValueError):
-        bq.SizeBinnedQueue(pad_to="none")
+        qa.submit(*[torch.zeros(k, dtype=torch.float64, device="cuda") for k in (2000, 2000 * 2000, 2000, 2000)])
 
 
 @pytest.mark.gpu
@@ -108,3 +110,69 @@ def test_submit_many_matches_single_submits():
     assert np.abs(v1.cpu().numpy() - np.array(want)).max() < 1e-10
     with pytest.raises(ValueError):
         q1.submit_many(4, ta[:8], tB[:32], tc[:8], td[:7])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_chunks_runs_and_shuffled_tickets(dtype):
+    """Chunks of one big allocation submitted in shuffled order (one contiguous run, tickets out of order), chunks from
+    separate allocations (gather), single chunks (zero copy), several n per bin; with and without variances."""
+    import torch
+    bq = pkg("binqueue")
+    dt = getattr(torch, dtype)
+    rng = np.random.default_rng(5)
+    tol = 1e-10 if dtype == "float64" else 5e-5
+    for with_e in (True, False):
+        q = bq.SizeBinnedQueue()
+        want = {}
+        keep = []
+        chunk_log, ticket_log = [], []
+
+        def add_group(n, count, pieces, shuffle):
+            B = spd_batch(n, count, seed=n + count)
+            a, c, d = (rng.random(count * n) for _ in range(3))
+            e = rng.random(count)
+            m = oracle.mean_batched(a, B, c, d, n)
+            v = oracle.variance_batched(a, B, c, e, n)
+            ta, tB, tc, td, te = (torch.from_numpy(x).to(dt).cuda() for x in (a, B, c, d, e))
+            keep.append((ta, tB, tc, td, te))
+            cuts = np.linspace(0, count, pieces + 1).astype(int)
+            order = list(range(pieces))
+            if shuffle:
+                order = order[::-1]
+            for k in order:
+                lo, hi = int(cuts[k]), int(cuts[k + 1])
+                if hi == lo:
+                    continue
+                ch = (ta[lo * n:hi * n], tB[lo * n * n:hi * n * n], tc[lo * n:hi * n], td[lo * n:hi * n]) + ((te[lo:hi],) if with_e else ())
+                t = q.submit_many(n, *ch)
+                chunk_log.append(ch)
+                ticket_log.append(t)
+                for i in range(hi - lo):
+                    want[t + i] = (m[lo + i], v[lo + i])
+
+        add_group(32, 300, 5, True)     # one run, tickets reversed
+        add_group(20, 64, 1, False)     # same bin, other n: its own launch, zero copy
+        add_group(128, 40, 4, False)    # one run, tickets in order
+        add_group(100, 17, 3, True)
+        add_group(32, 100, 2, False)    # second allocation with n = 32: two runs -> gathered
+        add_group(300, 3, 1, False)
+        add_group(7, 9, 3, True)
+        means, variances = q.flush()
+        torch.cuda.synchronize()
+        assert (variances is not None) == with_e
+        # the same chunks again through ONE C call (matinv_queue_submit_chunks)
+        table = q.chunk_table([(int(ts[0].numel() // (ts[1].numel() // ts[0].numel())), *ts) for ts in chunk_log])
+        firsts = q.submit_table(table)
+        assert firsts == ticket_log
+        m2, v2 = q.flush()
+        torch.cuda.synchronize()
+        assert torch.equal(m2, means) and (not with_e or torch.equal(v2, variances))
+        total = len(want)
+        assert means.numel() == total
+        wm = np.array([want[i][0] for i in range(total)])
+        assert np.abs(means.double().cpu().numpy() - wm).max() < tol
+        if with_e:
+            wv = np.array([want[i][1] for i in range(total)])
+            assert np.abs(variances.double().cpu().numpy() - wv).max() < tol
+        assert q.pending() == {}
