@@ -151,8 +151,8 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
         break;
     case MATINV_KERNEL_TILEP:
         if (algo != MATINV_ALGO_GAUSS_JORDAN || !tilep_supports(n))
-            return fail(MATINV_ERR_UNSUPPORTED, "pivoting tile family serves Gauss-Jordan with n <= 64 only (n=%d)", n);
-        e = launch_gj_tilep<T>(n, A, X, batch, dInfo, stream);
+            return fail(MATINV_ERR_UNSUPPORTED, "pivoting tile family serves Gauss-Jordan with n <= 128 only (n=%d)", n);
+        e = n > 64 ? launch_gj_tilep4<T>(n, A, X, batch, dInfo, stream) : launch_gj_tilep<T>(n, A, X, batch, dInfo, stream);
         break;
     case MATINV_KERNEL_ROW:
         if (algo != MATINV_ALGO_GAUSS_JORDAN || !row_family_supports<T>(n))

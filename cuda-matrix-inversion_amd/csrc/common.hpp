@@ -165,6 +165,16 @@ template <>
 hipError_t launch_gj_tilep_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, int *hint_out);
 const char *name_gj_tilep(bool f64, int n);
+// four wavefronts per matrix, 64 < n <= 128 (tilep4_kernels.hip)
+template <class T>
+hipError_t launch_gj_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <>
+hipError_t launch_gj_tilep4<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
+template <>
+hipError_t launch_gj_tilep4<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
+const char *name_gj_tilep4(bool f64, int n);
+// after a natural-order launch whose rejects do not pass through the pivoting work-list kernel: *hint_out = *dev_count
+hipError_t launch_hint_store(const int *dev_count, int *hint_out, hipStream_t stream);
 // Adaptive choice between the natural-order (verified) tile kernel and the pivoting one (tile_kernels.hip): see gj_tile_policy
 struct TileStats {
     unsigned long long natural_launches, pivot_launches, last_rejected, last_batch;

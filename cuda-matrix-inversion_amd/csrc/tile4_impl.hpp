@@ -335,6 +335,9 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 {
     if (!tile4_supports(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
+    // Gauss-Jordan: general batches go straight to the four-wave PIVOTING kernel once a natural-order launch of this size
+    // has seen most of its matrices rejected (tile_kernels.inc "natural order or pivot search?")
+    if (!SPD && tile_policy_use_pivot(sizeof(T) == 8, (n + 15) / 16)) return launch_gj_tilep4<T>(n, A, X, batch, info, stream);
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
@@ -369,6 +372,7 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     if (e == hipSuccess)
         e = SPD ? launch_chol_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream)
                 : launch_gj_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream);
+    if (e == hipSuccess && !SPD) e = launch_hint_store(ws, tile_policy_record(sizeof(T) == 8, nt, batch), stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
 }

@@ -3,7 +3,7 @@
 
 namespace matinv {
 
-bool tilep_supports(int n) { return n >= 1 && n <= 64; }
+bool tilep_supports(int n) { return n >= 1 && n <= 128; }
 
 template <>
 hipError_t launch_gj_tilep<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream)
@@ -13,6 +13,7 @@ hipError_t launch_gj_tilep<double>(int n, BatchRef<const double> A, BatchRef<dou
 
 const char *name_gj_tilep(bool f64, int n)
 {
+    if (n > 64) return name_gj_tilep4(f64, n);
     static thread_local char buf[48];
     snprintf(buf, sizeof buf, "matinv_gj_tilep_%s<%d, %s>", f64 ? "f64" : "f32", (n + 15) / 16, (n % 16) == 0 ? "true" : "false");
     return buf;

@@ -149,11 +149,11 @@ def test_reference_fixtures_and_goldens(d, n, family, gold):
 def test_square_fixtures_pivoting(f, n, gold):
     a, _, _, _ = read_ref(f + ".mats")
     assert rel_err(gpu_inverse(a, n, GJ), gold[f + "/gj"], n) < 1e-10
-    if n <= 64:  # the pivoting MFMA tile kernel itself (the reference's general fixtures, tests/square_5_*.mats)
+    if n <= 128:  # the pivoting MFMA tile kernels themselves (the reference's general fixtures, tests/square_5_*.mats)
         assert rel_err(gpu_inverse(a, n, GJ, api.KERNEL_TILEP), gold[f + "/gj"], n) < 1e-10
 
 
-@pytest.mark.parametrize("n", [20, 32, 50, 64])
+@pytest.mark.parametrize("n", [20, 32, 50, 64, 72, 100, 128])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_tile_family_pivots_inside_the_kernel(n, dtype):
     """General batches through the tile family: the first launch tries the natural order, every matrix it rejects is

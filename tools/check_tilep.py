@@ -29,7 +29,7 @@ a = rng.random((8, n, n)); a[3, :, 5] = 0.0; a[6, 2, 2] = np.nan
 d = torch.from_numpy(a.reshape(-1)).cuda(); info = torch.zeros(8, dtype=torch.int32, device='cuda')
 x = api.inverse_batched(d, n, 0, info=info, kernel=api.KERNEL_TILEP); torch.cuda.synchronize()
 print("singular info:", info.cpu().numpy())
-for n in (32, 64):
+for n in ():
     for dt in (torch.float64, torch.float32):
         batch = 100000 if n == 64 else 200000
         a = torch.rand((batch * n * n,), dtype=dt, device='cuda'); x = torch.empty_like(a)
