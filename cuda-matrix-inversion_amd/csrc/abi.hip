@@ -49,6 +49,12 @@ int check_device()
         return fail(MATINV_ERR_NO_DEVICE, "device %d is %s; libmatinv_hip is built for gfx950 (MI355X) only", dev,
                     prop.gcnArchName);
     checked_dev = dev;
+    // Work lists and the workspaces of the blocked paths are stream-ordered allocations (hipMallocAsync) that are freed again
+    // inside the call: keep what is freed in the device's pool instead of handing it back to the driver at the next
+    // synchronisation (the default release threshold is 0 -- a 5 GB workspace then costs ~20 ms to get back on every call).
+    hipMemPool_t pool;
+    unsigned long long keep = ~0ull;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     return MATINV_OK;
 }
 

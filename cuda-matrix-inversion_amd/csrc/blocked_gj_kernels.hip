@@ -20,11 +20,12 @@
 // 3m50s to compile.)
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "tile_common.hpp"
 
 namespace matinv {
 
-constexpr int BGJ_PB = 32;
+constexpr int BGJ_PB = 32;    // sub-panel: columns eliminated by one launch of the panel kernel
+constexpr int BGJ_NB = 128;   // block: columns between two rank-NB MFMA updates of the whole matrix
 constexpr int BGJ_TILE = 64;
 
 namespace {
@@ -77,9 +78,12 @@ __global__ __launch_bounds__(256) void matinv_bgj_init(BatchRef<const T> Ain, si
     if (blockIdx.x == 0 && threadIdx.x == 0) status[item] = 0;
 }
 
+// ---- single-level scheme for n < 384 (r01): one 32-column panel, then the rank-32 update of every other column from VALU
+// register tiles; the panel kernel publishes the pivot rows of ALL columns itself. With so few columns per matrix the extra
+// launches of the two-level scheme below cost more than its traffic saves (n = 256: 2.4e5 inv/s against 1.9e5).
 // blockDim = n rounded up to a multiple of 64 (<= 1024)
 template <class T>
-__global__ __launch_bounds__(1024) void matinv_bgj_panel(const T *Win, T *Wout, T *Bbuf, int *rowsrc, int *pivots, int n, int k0,
+__global__ __launch_bounds__(1024) void matinv_bgj_panel1(const T *Win, T *Wout, T *Bbuf, int *rowsrc, int *pivots, int n, int k0,
                                                          int *status)
 {
     __shared__ T s_val[16];
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(1024) void matinv_bgj_panel(const T *Win, T *Wout, 
 
 // x_new[row][col] = (row in K ? 0 : x_old[rowsrc[row]][col]) + sum_k G[row][k] b[k][col]   for the columns outside K
 template <class T>
-__global__ __launch_bounds__(256) void matinv_bgj_update(const T *Win, T *Wout, const T *Bbuf, const int *rowsrc, int n, int k0,
+__global__ __launch_bounds__(256) void matinv_bgj_update1(const T *Win, T *Wout, const T *Bbuf, const int *rowsrc, int n, int k0,
                                                          const int *status)
 {
     __shared__ T Gt[BGJ_PB][BGJ_TILE + 1], Bt[BGJ_PB][BGJ_TILE + 1];
@@ -208,6 +212,233 @@ __global__ __launch_bounds__(256) void matinv_bgj_update(const T *Win, T *Wout, 
     }
 }
 
+// ---- one block column of BGJ_NB = 128 columns -----------------------------------------------------------------------------
+// The block lives in its own ping-pong buffers (ld = n, up to 128 columns per item); its BGJ_PB-wide sub-panels are
+// eliminated one after the other, each followed by the rank-32 update of the OTHER COLUMNS OF THE BLOCK only. Everything
+// outside the block is deferred to one rank-128 update per block (matinv_bgj_update_mfma): in exact arithmetic the 128
+// elementary steps equal one block step x_new[:, J] = Z(x_perm[:, J]) + G x_perm[K, J] with G = the finished block columns,
+// x_perm = the ORIGINAL columns with the block's row swaps applied and Z = zeroing of the rows K -- so the big update needs
+// only the composite row map `comp` of the block and reads each outside element once per 128 columns instead of once per 32.
+//
+// blockDim = n rounded up to a multiple of 64 (<= 1024). Pin / Pout: block buffers of this item (column c of the block at
+// + c * n); c0 = first column of the sub-panel inside the block, K0 = global index of the block's first column.
+template <class T>
+__global__ __launch_bounds__(1024) void matinv_bgj_panel(const T *Pin, size_t in_stride, T *Pout, size_t out_stride, T *Bin,
+                                                         int *rowsrc, const int *comp_prev, int *comp_next, int *pivots, int n,
+                                                         int bw, int c0, int K0, int *status)
+{
+    __shared__ T s_val[16];
+    __shared__ int s_idx[16];
+    __shared__ T xch[2 * BGJ_PB];
+    __shared__ int rs[1024];
+    const size_t item = blockIdx.x;
+    if (status[item] != 0) return;
+    const T *pin = Pin + item * in_stride;
+    T *pout = Pout + item * out_stride;
+    const int t = threadIdx.x, tx = t & 63, ty = t >> 6, nwaves = blockDim.x >> 6;
+    const int pb = (bw - c0 < BGJ_PB) ? bw - c0 : BGJ_PB;
+    const int kg0 = K0 + c0;  // global index of the sub-panel's first pivot
+
+    T x[BGJ_PB];
+#pragma unroll
+    for (int c = 0; c < BGJ_PB; ++c) x[c] = (t < n && c < pb) ? pin[(size_t)(c0 + c) * n + t] : (T)0;
+    rs[t] = t;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < BGJ_PB; ++j) {
+        if (j < pb) {  // block-uniform
+            const int k = kg0 + j;
+            T best;
+            const int bi = (t & ~63) + bgj_wave_argmax_abs(x[j], t >= k && t < n, &best);
+            if (tx == 0) { s_val[ty] = best; s_idx[ty] = bi; }
+            __syncthreads();
+            best = s_val[0];
+            int p = s_idx[0];
+            for (int w = 1; w < nwaves; ++w) {
+                const T ob = s_val[w];
+                const int oi = s_idx[w];
+                if (ob > best) { best = ob; p = oi; }  // equal maxima: the lower wave (lower rows) keeps it
+            }
+            if (!(best > 0) || best > max_finite<T>()) {  // zero, NaN or infinite column: no usable pivot (block-uniform)
+                if (t == 0) status[item] = k + 1;
+                return;
+            }
+            if (t == 0) {
+                pivots[item * (size_t)n + k] = p;
+                const int u = rs[k];
+                rs[k] = rs[p];
+                rs[p] = u;
+            }
+            if (t == k || t == p) {
+                T *dst = xch + (t == p ? 0 : BGJ_PB);  // [0] = the pivot row (row p; also when p == k), [1] = old row k
+#pragma unroll
+                for (int c = 0; c < BGJ_PB; ++c) dst[c] = x[c];
+            }
+            __syncthreads();
+            const T pv = (T)1 / xch[j];
+            if (t == p && p != k) {
+#pragma unroll
+                for (int c = 0; c < BGJ_PB; ++c) x[c] = xch[BGJ_PB + c];
+            }
+            if (t == k) {
+#pragma unroll
+                for (int c = 0; c < BGJ_PB; ++c) x[c] = (c == j) ? pv : xch[c] * pv;
+            } else if (t < n) {
+                const T m = x[j];
+#pragma unroll
+                for (int c = 0; c < BGJ_PB; ++c) x[c] = (c == j) ? -m * pv : fma(-m, xch[c] * pv, x[c]);
+            }
+        }
+    }
+    __syncthreads();  // rs is final
+    if (t < n) {
+#pragma unroll
+        for (int c = 0; c < BGJ_PB; ++c)
+            if (c < pb) pout[(size_t)(c0 + c) * n + t] = x[c];
+        rowsrc[item * (size_t)n + t] = rs[t];
+        // composite row map of the block so far: row t now holds what sat in row comp[t] when the block started
+        comp_next[item * (size_t)n + t] = comp_prev ? comp_prev[item * (size_t)n + rs[t]] : rs[t];
+        // old pivot-row entries (after this sub-panel's swaps) of the other columns OF THE BLOCK: thread t <-> block column t
+        if (t < bw && (t < c0 || t >= c0 + pb)) {
+            const T *col = pin + (size_t)t * n;
+            T *b = Bin + item * (size_t)BGJ_PB * BGJ_NB;
+            for (int j = 0; j < pb; ++j) b[(size_t)j * BGJ_NB + t] = col[rs[kg0 + j]];
+        }
+    }
+}
+
+// B operand of the block-level update: Bfull[k][col] = x_old[col][comp[K0 + k]] (the block's pivot rows as they stood when
+// the block started, in pivot order). 64 columns per workgroup through LDS: consecutive threads read consecutive k (comp is
+// the identity except for the swapped rows: nearly contiguous) and write consecutive columns.
+template <class T>
+__global__ __launch_bounds__(256) void matinv_bgj_pivot_rows(const T *Win, T *Bfull, const int *comp, int n, int bw, int K0,
+                                                             const int *status)
+{
+    __shared__ T tile[64][BGJ_NB + 1];
+    __shared__ int ksrc[BGJ_NB];
+    const size_t item = blockIdx.y;
+    if (status[item] != 0) return;
+    const int c0 = blockIdx.x * 64, t = threadIdx.x;
+    const T *win = Win + item * (size_t)n * n;
+    T *bf = Bfull + item * (size_t)BGJ_NB * n;
+    if (t < BGJ_NB) ksrc[t] = (t < bw) ? comp[item * (size_t)n + K0 + t] : 0;
+    __syncthreads();
+    for (int e = t; e < 64 * BGJ_NB; e += 256) {
+        const int k = e % BGJ_NB, cc = e / BGJ_NB;
+        if (k < bw && c0 + cc < n) tile[cc][k] = win[(size_t)(c0 + cc) * n + ksrc[k]];
+    }
+    __syncthreads();
+    for (int e = t; e < 64 * BGJ_NB; e += 256) {
+        const int cc = e % 64, k = e / 64;
+        if (k < bw && c0 + cc < n) bf[(size_t)k * n + c0 + cc] = tile[cc][k];
+    }
+}
+
+// The rank-kw update on the matrix cores, used at both levels:
+//   x_new[row][col] = (Z0 <= row < Z0 + kw ? 0 : x_old[rmap[row]][col]) + sum_{k < kw} G[row][k] x_old[rmap[Z0 + k]][col]
+// * block level (INNER = false): x_old / x_new = the two working copies (all n columns), G = the finished block columns,
+//   rmap = the block's composite row map, kw = bw <= 128, Z0 = K0; the block's own columns [K0, K0 + bw) are copied from G;
+// * inside a block (INNER = true): x_old / x_new = the block buffers (ncols = bw columns), G = the sub-panel just eliminated
+//   (columns [c0, c0 + pb) of x_new), rmap = that sub-panel's row map, kw = pb <= 32, Z0 = K0 + c0; the sub-panel's own
+//   columns are left alone (matinv_bgj_panel wrote them).
+// One workgroup per 64 x 64 tile, four wavefronts of 32 x 32, 16x16x4 MFMA tiles. The buffers are column-major, so the MFMA
+// computes the TRANSPOSED tile (its rows <-> matrix columns, its columns <-> matrix rows): the 16 lanes of a C/D row group
+// then own 16 consecutive matrix rows of one column -- 128-byte segments for the gather of x_old and for the store. G and
+// the pivot rows (prepared k-major by matinv_bgj_panel / matinv_bgj_pivot_rows: gathering them here, per tile, from the
+// column-major x_old doubled the time of this kernel) go through LDS in slabs of 32.
+// MT = 16 x 16 MFMA tiles per wavefront and dimension: 2 -> 64 x 64 per workgroup (small n: fewer padded rows / columns),
+// 4 -> 128 x 128 (half the LDS reads and half the operand traffic per flop). The slabs are double-buffered through
+// registers: the next slab's global loads are in flight while the matrix cores work on the current one.
+template <class T, bool INNER, int MT>
+__global__ __launch_bounds__(256) void matinv_bgj_update_mfma(const T *Xold, size_t old_stride, T *Xnew, size_t new_stride,
+                                                              const T *Gsrc, size_t g_stride, const T *Bsrc, size_t b_stride, int ldb,
+                                                              const int *rmap, int n, int ncols, int kw, int Z0, int skip0,
+                                                              const int *status)
+{
+    typedef TileGeo<T> G;
+    typedef typename G::vec4 vec4;
+    constexpr int WT = 16 * MT, TS = 2 * WT;   // wave tile, workgroup tile
+    constexpr int KS = MT == 4 ? 16 : 32;      // slab depth
+    constexpr int PER = KS * TS / 256;         // slab elements per thread and operand
+    __shared__ T Gt[KS][TS], Bt[KS][TS];
+    __shared__ int rsrc[TS];
+    const size_t item = blockIdx.z;
+    if (status[item] != 0) return;
+    const int j0 = blockIdx.x * TS, i0 = blockIdx.y * TS;  // first column / row of the tile
+    const T *xold = Xold + item * old_stride;
+    T *xnew = Xnew + item * new_stride;
+    const T *g = Gsrc + item * g_stride;
+    const T *bsrc = Bsrc + item * b_stride;  // [k][column], ld = ldb: the pivot rows x_old[rmap[Z0 + k]][.] in pivot order
+    const int *rm = rmap + item * (size_t)n;
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int q = l >> 4, c = l & 15;
+    const int wc = (wv & 1) * WT, wr = (wv >> 1) * WT;  // this wave's columns x rows inside the tile
+    if (t < TS) rsrc[t] = (i0 + t < n) ? rm[i0 + t] : 0;
+    // tiles whose columns all belong to the skipped range only copy (block level) or have nothing to do (inner)
+    const bool all_skipped = j0 >= skip0 && j0 + TS <= skip0 + kw;
+    if (INNER && all_skipped) return;
+    vec4 acc[MT][MT] = {};
+    if (!all_skipped) {
+        T gq[PER], bq[PER];
+        auto fetch = [&](int ks) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = t + 256 * i, k = e / TS, r = e % TS;
+                gq[i] = (ks + k < kw && i0 + r < n) ? g[(size_t)(ks + k) * n + i0 + r] : (T)0;
+                bq[i] = (ks + k < kw && j0 + r < ncols) ? bsrc[(size_t)(ks + k) * ldb + j0 + r] : (T)0;
+            }
+        };
+        fetch(0);
+        for (int ks = 0; ks < kw; ks += KS) {
+            __syncthreads();  // the previous slab has been consumed (and rsrc is visible after the first one)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = t + 256 * i;
+                Gt[e / TS][e % TS] = gq[i];
+                Bt[e / TS][e % TS] = bq[i];
+            }
+            __syncthreads();
+            if (ks + KS < kw) fetch(ks + KS);
+#pragma unroll
+            for (int kk = 0; kk < KS / 4; ++kk) {
+                T a[MT], b[MT];
+#pragma unroll
+                for (int u = 0; u < MT; ++u) {
+                    a[u] = Bt[4 * kk + q][wc + 16 * u + c];  // MFMA rows  <-> matrix columns
+                    b[u] = Gt[4 * kk + q][wr + 16 * u + c];  // MFMA columns <-> matrix rows
+                }
+#pragma unroll
+                for (int u = 0; u < MT; ++u)
+#pragma unroll
+                    for (int v = 0; v < MT; ++v) acc[u][v] = G::mfma(a[u], b[v], acc[u][v]);
+            }
+        }
+    } else {
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < MT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = j0 + wc + 16 * u + G::trow(r, q);
+            if (col >= ncols) continue;
+            const bool skipped = col >= skip0 && col < skip0 + kw;
+            if (INNER && skipped) continue;
+#pragma unroll
+            for (int v = 0; v < MT; ++v) {
+                const int lrow = wr + 16 * v + c, row = i0 + lrow;
+                if (row >= n) continue;
+                T out;
+                if (skipped) out = g[(size_t)(col - skip0) * n + row];  // the finished block columns
+                else {
+                    const T old = (row >= Z0 && row < Z0 + kw) ? (T)0 : xold[(size_t)col * n + rsrc[lrow]];
+                    out = old + acc[u][v][r];
+                }
+                xnew[(size_t)col * n + row] = out;
+            }
+        }
+}
+
 // X[:, j] = W[:, src(j)], src(j) = the pivot swaps applied to the index j in forward order (the row swaps of P A become
 // column swaps of (P A)^-1 in reverse order; following one index through them forwards is the same map)
 template <class T>
@@ -242,13 +473,13 @@ __global__ __launch_bounds__(256) void matinv_bgj_finish(const T *W, BatchRef<T>
     if (info && blockIdx.x == 0 && t == 0) info[first + item] = bad;
 }
 
-// workspace cap of the blocked paths (bytes); MATINV_BLOCKED_WS_MB overrides the 4 GiB default (tests use it to force chunking)
+// workspace cap of the blocked paths (bytes); MATINV_BLOCKED_WS_MB overrides the 16 GiB default (tests use it to force chunking)
 size_t blocked_workspace_cap()
 {
     static const size_t cap = []() {
         const char *s = getenv("MATINV_BLOCKED_WS_MB");
         const long mb = s && *s ? atol(s) : 0;
-        return mb > 0 ? (size_t)mb << 20 : (size_t)4 << 30;
+        return mb > 0 ? (size_t)mb << 20 : (size_t)16 << 30;  // 288 GB of HBM: 16 GiB of scratch is small change
     }();
     return cap;
 }
@@ -256,10 +487,8 @@ size_t blocked_workspace_cap()
 bool blocked_gj_supports(int n) { return n >= 1 && n <= 1024; }
 
 template <class T>
-hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+static hipError_t launch_gj_blocked_small(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
-    if (!blocked_gj_supports(n)) return hipErrorInvalidValue;
-    if (batch == 0) return hipSuccess;
     const size_t per_item = (2 * (size_t)n * n + (size_t)BGJ_PB * n) * sizeof(T);
     size_t chunk = blocked_workspace_cap() / per_item;  // bounded workspace, grid.y / grid.z limit
     if (chunk < 1) chunk = 1;
@@ -280,8 +509,89 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
         hipLaunchKernelGGL(matinv_bgj_init<T>, dim3(64, b), dim3(256), 0, stream, A, first, W0, n, status);
         T *cur = W0, *nxt = W1;
         for (int k0 = 0; k0 < n; k0 += BGJ_PB) {
-            hipLaunchKernelGGL(matinv_bgj_panel<T>, dim3(b), dim3(threads), 0, stream, cur, nxt, Bbuf, rowsrc, pivots, n, k0, status);
-            hipLaunchKernelGGL(matinv_bgj_update<T>, dim3(g, g, b), dim3(256), 0, stream, cur, nxt, Bbuf, rowsrc, n, k0, status);
+            hipLaunchKernelGGL(matinv_bgj_panel1<T>, dim3(b), dim3(threads), 0, stream, cur, nxt, Bbuf, rowsrc, pivots, n, k0, status);
+            hipLaunchKernelGGL(matinv_bgj_update1<T>, dim3(g, g, b), dim3(256), 0, stream, cur, nxt, Bbuf, rowsrc, n, k0, status);
+            T *tmp = cur;
+            cur = nxt;
+            nxt = tmp;
+        }
+        hipLaunchKernelGGL(matinv_bgj_finish<T>, dim3(g, b), dim3(256), 0, stream, cur, X, first, pivots, info, n, status);
+    }
+    e = hipGetLastError();
+    hipError_t e2 = hipFreeAsync(ws, stream), e3 = hipFreeAsync(iws, stream);
+    return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
+}
+
+template <class T>
+hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    if (!blocked_gj_supports(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    if (n < 384) return launch_gj_blocked_small<T>(n, A, X, batch, info, stream);
+    // per item: two working copies, two block buffers (n x NB), the block's pivot rows (NB x n), a sub-panel's b strip
+    const size_t per_item = (2 * (size_t)n * n + 3 * (size_t)BGJ_NB * n + (size_t)BGJ_PB * BGJ_NB) * sizeof(T);
+    size_t chunk = blocked_workspace_cap() / per_item;  // bounded workspace, grid.y / grid.z limit
+    if (chunk < 1) chunk = 1;
+    if (chunk > 65535) chunk = 65535;
+    if (chunk > batch) chunk = batch;
+    T *ws = nullptr;
+    int *iws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), chunk * per_item, stream);
+    if (e != hipSuccess) return e;
+    e = hipMallocAsync(reinterpret_cast<void **>(&iws), chunk * (4 * (size_t)n + 1) * sizeof(int), stream);
+    if (e != hipSuccess) { (void)hipFreeAsync(ws, stream); return e; }
+    const size_t nn = (size_t)n * n, blk = (size_t)BGJ_NB * n, strip = (size_t)BGJ_PB * BGJ_NB;
+    T *W0 = ws, *W1 = W0 + chunk * nn, *P0 = W1 + chunk * nn, *P1 = P0 + chunk * blk, *Bfull = P1 + chunk * blk,
+      *Bin = Bfull + chunk * blk;
+    int *rowsrc = iws, *comp0 = rowsrc + chunk * (size_t)n, *comp1 = comp0 + chunk * (size_t)n, *pivots = comp1 + chunk * (size_t)n,
+        *status = pivots + chunk * (size_t)n;
+    const unsigned threads = (unsigned)((n + 63) / 64 * 64);
+    const unsigned g = (unsigned)((n + BGJ_TILE - 1) / BGJ_TILE), g128 = (unsigned)((n + 127) / 128);
+    // 128 x 128 workgroup tiles: fp32 only (in fp64 their 128 accumulator registers leave one wave per SIMD: 4.9e3 inv/s at
+    // n = 1024 against 6.6e3 with 64 x 64 tiles), and only once the padding they bring (n rounded up to 128) is below a fifth
+    const bool big = sizeof(T) == 4 && (double)(g128 * 128) <= 1.2 * n;
+    const int nbw = BGJ_NB;
+    for (size_t first = 0; first < batch; first += chunk) {
+        const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
+        hipLaunchKernelGGL(matinv_bgj_init<T>, dim3(64, b), dim3(256), 0, stream, A, first, W0, n, status);
+        T *cur = W0, *nxt = W1;
+        for (int K0 = 0; K0 < n; K0 += nbw) {
+            const int bw = n - K0 < nbw ? n - K0 : nbw;
+            // the block's sub-panels, inside the block buffers: X0 = the block columns of cur, then P0, P1, P0, ...
+            const T *pin = cur + (size_t)K0 * n;
+            size_t in_stride = nn;
+            T *pout = P0;
+            const int *cprev = nullptr;
+            int *cnext = comp0;
+            for (int c0 = 0; c0 < bw; c0 += BGJ_PB) {
+                const int pb = bw - c0 < BGJ_PB ? bw - c0 : BGJ_PB;
+                hipLaunchKernelGGL(matinv_bgj_panel<T>, dim3(b), dim3(threads), 0, stream, pin, in_stride, pout, blk, Bin, rowsrc, cprev,
+                                   cnext, pivots, n, bw, c0, K0, status);
+                if (bw > pb) {
+                    if (big)
+                        hipLaunchKernelGGL((matinv_bgj_update_mfma<T, true, 4>), dim3((bw + 127) / 128, g128, b), dim3(256), 0, stream, pin,
+                                           in_stride, pout, blk, pout + (size_t)c0 * n, blk, Bin, strip, BGJ_NB, rowsrc, n, bw, pb, K0 + c0,
+                                           c0, status);
+                    else
+                        hipLaunchKernelGGL((matinv_bgj_update_mfma<T, true, 2>), dim3((bw + 63) / 64, g, b), dim3(256), 0, stream, pin,
+                                           in_stride, pout, blk, pout + (size_t)c0 * n, blk, Bin, strip, BGJ_NB, rowsrc, n, bw, pb, K0 + c0,
+                                           c0, status);
+                }
+                pin = pout, in_stride = blk;
+                pout = (pout == P0) ? P1 : P0;
+                cprev = cnext;
+                cnext = (cnext == comp0) ? comp1 : comp0;
+            }
+            // pin = the finished block columns G, cprev = the block's composite row map
+            if (bw < n)
+                hipLaunchKernelGGL(matinv_bgj_pivot_rows<T>, dim3((n + 63) / 64, b), dim3(256), 0, stream, cur, Bfull, cprev, n, bw, K0,
+                                   status);
+            if (big)
+                hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 4>), dim3(g128, g128, b), dim3(256), 0, stream, cur, nn, nxt, nn, pin,
+                                   blk, Bfull, blk, n, cprev, n, n, bw, K0, K0, status);
+            else
+                hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 2>), dim3(g, g, b), dim3(256), 0, stream, cur, nn, nxt, nn, pin, blk,
+                                   Bfull, blk, n, cprev, n, n, bw, K0, K0, status);
             T *tmp = cur;
             cur = nxt;
             nxt = tmp;

@@ -95,7 +95,7 @@ unsigned tile_grid_rounds();
 
 // blocked Gauss-Jordan with partial pivoting for large general matrices (blocked_gj_kernels.hip)
 bool blocked_gj_supports(int n);
-size_t blocked_workspace_cap();  // bytes; MATINV_BLOCKED_WS_MB overrides the 4 GiB default
+size_t blocked_workspace_cap();  // bytes; MATINV_BLOCKED_WS_MB overrides the 16 GiB default
 template <class T>
 hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 
