@@ -162,7 +162,7 @@ def test_chunks_runs_and_shuffled_tickets(dtype):
         torch.cuda.synchronize()
         assert (variances is not None) == with_e
         # the same chunks again through ONE C call (matinv_queue_submit_chunks)
-        table = q.chunk_table([(int(ts[0].numel() // (ts[1].numel() // ts[0].numel())), *ts) for ts in chunk_log])
+        table = q.chunk_table([(int(ts[1].numel() // ts[0].numel()), *ts) for ts in chunk_log])
         firsts = q.submit_table(table)
         assert firsts == ticket_log
         m2, v2 = q.flush()

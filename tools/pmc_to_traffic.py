@@ -27,7 +27,8 @@ for kern, v in vals.items():
         continue
     m = re.search(r"<(?:double, )?(\d+)", kern)
     rd, wr = 2.0 * v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
-    n = {"matinv_gj_tile_f64": 16, "matinv_spd_tile_f64": 16, "matinv_gj_tile4_f64": 16}.get(kern.split("<")[0], 1) * int(m.group(1))
+    n = {"matinv_gj_tile_f64": 16, "matinv_spd_tile_f64": 16, "matinv_gj_tile4_f64": 16, "matinv_gj_tilep_f64": 16,
+         "matinv_gj_tilep4_f64": 16}.get(kern.split("<")[0], 1) * int(m.group(1))
     table[f"{kern}|n={n}"] = rd + wr
     table[f"{kern}|n={n}|detail"] = {"batch": batch, "read_bytes": rd, "write_bytes": wr,
                                      "algorithmic_bytes": batch * 2 * n * n * 8,
