@@ -19,13 +19,23 @@ for ln in open(src):
     f = ln.split(None, 4)
     if len(f) < 5 or f[1] not in ("FETCH_SIZE", "WRITE_SIZE"):
         continue
-    vals.setdefault(f[4].strip(), {})[f[1]] = float(f[2])
+    # a kernel may show up in several workloads' passes (the natural-order kernel also runs once, rejecting everything, in
+    # the GENERAL workloads): keep, per kernel, the workload in which it moved the most bytes -- its full job
+    vals.setdefault((f[0].rsplit("_", 2)[0], f[4].strip()), {})[f[1]] = float(f[2])
 path = os.path.join(os.path.dirname(src), "traffic.json")
 table = {}
-for kern, v in vals.items():
-    if "worklist" in kern or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+best = {}
+for (wl, kern), v in vals.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        tot = 2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]
+        if kern not in best or tot > best[kern][0]:
+            best[kern] = (tot, v)
+for kern, (_, v) in best.items():
+    if "worklist" in kern:
         continue
     m = re.search(r"<(?:double, )?(\d+)", kern)
+    if not m:
+        continue
     rd, wr = 2.0 * v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
     n = {"matinv_gj_tile_f64": 16, "matinv_spd_tile_f64": 16, "matinv_gj_tile4_f64": 16, "matinv_gj_tilep_f64": 16,
          "matinv_gj_tilep4_f64": 16}.get(kern.split("<")[0], 1) * int(m.group(1))
