@@ -134,6 +134,8 @@ def run_mixed(args, api, device, rank, world):
     1024: 8 -- roughly equal flops per bin is NOT attempted; per-bin rates are reported. One step = submit + flush."""
     bq = importlib.import_module(PKG + ".binqueue")
     mix = {32: 16384, 128: 2048, 512: 32, 1024: 8}
+    if os.environ.get("MATINV_MIX"):  # experiments only, e.g. MATINV_MIX=32:16384,128:2048
+        mix = {int(k): int(v) for k, v in (kv.split(":") for kv in os.environ["MATINV_MIX"].split(","))}
     g = torch.Generator(device=device).manual_seed(0x5EED + rank)
     items, chunks = [], []
     CH = 256  # items arrive in same-size chunks of up to 256 (submit_many); the sizes are interleaved chunk by chunk
@@ -178,6 +180,17 @@ def run_mixed(args, api, device, rank, world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=backend_dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t[0].item())
+    # host work of one step by itself: submit + flush timed with the device idle (in the timed loop above the host runs ahead
+    # of the device and then waits inside flush for the previous step's results, so its share there is not host WORK)
+    idle = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        q.submit_table(table)
+        q.flush()
+        idle.append(time.perf_counter() - t_)
+    torch.cuda.synchronize()
+    host_idle_ms = float(np.median(idle)) * 1e3
     per_bin = {}
     for n, cnt in mix.items():  # kernel-only rate of each bin (batched, device resident)
         sel = [it for it in items if it[0].numel() == n]
@@ -203,7 +216,8 @@ def run_mixed(args, api, device, rank, world):
             "config": {"workload": "mixed: fp32 mean pipeline, size-binned queues 32/128/512/1024 (BASELINE configs[4])",
                        "mix_items_per_step_per_gpu": mix, "queue": "C (matinv_queue_*, csrc/queue.hip)",
                        "includes": "submit of same-size chunks of <= 256 items (sizes interleaved) + flush: segmented gather + one fused launch per size, one stream per bin"},
-            "host_ms_per_step": host_s[0] / args.steps * 1e3, "host_share": host_s[0] / elapsed,
+            "host_ms_per_step": host_idle_ms, "host_share": host_idle_ms / (elapsed / args.steps * 1e3),
+            "host_ms_in_calls_back_to_back": host_s[0] / args.steps * 1e3,
             "per_bin": per_bin}), flush=True)
 
 
@@ -414,8 +428,8 @@ def main():
             ms2 = float(np.mean(time_launches(lambda: api.inverse_batched(a2, n2, algo2, out=x2, batch=b2), 5)))
             r1, r2 = rooflines(algo2_name, n2, b2, ms2)
             kname2 = api.kernel_name(algo2, api.F64, n2)
-            if wname in GENERAL and n2 <= 64:
-                kname2 = api.kernel_name(algo2, api.F64, n2, api.KERNEL_TILEP)
+            if wname in GENERAL and 16 < n2 <= 128:
+                kname2 = api.kernel_name(algo2, api.F64, n2, api.KERNEL_TILEP)  # where the adaptive dispatch sends a general batch
             others[wname] = {"kernel": kname2, "batch": b2, "kernel_ms": ms2, "input": "general U(0,1)" if wname in GENERAL else "SPD",
                              "inversions_per_s": b2 / (ms2 * 1e-3), "bound": r1["bound"], "frac": r1["frac"],
                              "achieved": r1["achieved"], "unit": r1["unit"],
@@ -425,7 +439,7 @@ def main():
     if rank == 0:
         value = total_batch * args.steps / elapsed
         kname = api.kernel_name(algo, api.F64, n, kernel)
-        if general and n <= 64 and kernel == api.KERNEL_AUTO:
+        if general and 16 < n <= 128 and kernel == api.KERNEL_AUTO:
             kname = api.kernel_name(algo, api.F64, n, api.KERNEL_TILEP)  # where the adaptive dispatch sends a general batch
         roof, roof_other = rooflines(algo_name, n, batch, kern_ms)
         traffic, traffic_src = load_traffic(kname, n, batch)

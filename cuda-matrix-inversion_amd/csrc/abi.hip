@@ -650,7 +650,13 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     case MATINV_KERNEL_TILEP: return name_gj_tilep(f64, n);
     case MATINV_KERNEL_GLOBAL: return algo == MATINV_ALGO_CHOLESKY ? name_chol_global(f64) : name_gj_global(f64);
     case MATINV_KERNEL_BLOCKED:
-        if (algo == MATINV_ALGO_GAUSS_JORDAN) return f64 ? "matinv_bgj_update<double>" : "matinv_bgj_update<float>";
+        if (algo == MATINV_ALGO_GAUSS_JORDAN) {
+            // the kernel that dominates: the rank-128 MFMA update of the two-level scheme from n = 384 (128 x 128 workgroup
+            // tiles in fp32 when n rounded up to 128 wastes less than a fifth), the rank-32 VALU update below
+            if (n < 384) return f64 ? "matinv_bgj_update1<double>" : "matinv_bgj_update1<float>";
+            if (f64) return "matinv_bgj_update_mfma<double, false, 2>";
+            return ((n + 127) / 128) * 128 <= 1.2 * n ? "matinv_bgj_update_mfma<float, false, 4>" : "matinv_bgj_update_mfma<float, false, 2>";
+        }
         return f64 ? "matinv_bgp_panel<double>" : "matinv_bgp_panel<float>";
     default: return "";
     }

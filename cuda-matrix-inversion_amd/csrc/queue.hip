@@ -5,8 +5,8 @@
 // An item is (a, B, c, d[, e]) of some n <= the largest bin; items arrive as CHUNKS of `count` equally sized items that lie
 // back to back in device memory (count = 1 is allowed). submit() only records the chunk (five pointers, n, count, first
 // ticket) in the queue of the smallest bin that holds n: no device work, no per-item host work. flush() turns every
-// non-empty bin into launches of the fused mean / variance kernels on the bin's own HIP stream, so the bins overlap on the
-// device (largest bin first: its launches are the long ones):
+// non-empty bin into launches of the fused mean / variance kernels; the largest pending bin runs on one HIP stream, the other
+// bins on a second one, so the long launch chain of the large matrices overlaps the rest:
 //   * chunks of one bin are grouped by their EXACT n -- the kernels take n at run time and pad a matrix to their tile size
 //     with an identity block in registers ("device-side padding"), so nothing is padded or copied in memory to reach a bin
 //     size (the sketch's pad-to-the-bin policy would make an n = 40 item cost what a 128 x 128 one does);
@@ -224,6 +224,14 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
     std::vector<Launch> plan;
     hipError_t e = hipSuccess;
     int rc = MATINV_OK;
+    // Two streams, not one per bin: the largest pending bin (a latency-bound chain of many small launches) runs beside
+    // everything else. Measured on configs[4]'s mix: one stream per bin 2.05 ms per step (the cross-queue dependencies of
+    // four forks and four joins cost more than the overlap buys; 2.8 ms with 8 hardware queues), two streams 1.3-1.6 ms.
+    int top = -1;
+    for (int b = (int)q->bins.size() - 1; b >= 0 && top < 0; --b)
+        if (!q->q[b].empty()) top = b;
+    auto stream_of = [&](int b) { return q->streams[b == top ? 0 : ((int)q->streams.size() > 1 ? 1 : 0)]; };
+    auto slot_of = [&](int b) { return b == top ? 0 : ((int)q->streams.size() > 1 ? 1 : 0); };
 
     // ---- plan (host, O(chunks))
     for (int b = (int)q->bins.size() - 1; b >= 0 && e == hipSuccess; --b) {
@@ -257,7 +265,7 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
                 // 256-byte aligned sub-buffers of one stream-ordered allocation
                 auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
                 const size_t total = one_run ? al(sc) * 2 : al(vec) * 3 + al(mat) + al(sc) * 3;
-                e = hipMallocAsync(reinterpret_cast<void **>(&L.staging), total, q->streams[b]);
+                e = hipMallocAsync(reinterpret_cast<void **>(&L.staging), total, stream_of(b));
                 if (e != hipSuccess) break;
                 char *p = L.staging;
                 if (!one_run) {
@@ -319,13 +327,13 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
 
     // ---- launches: every bin on its own stream, forked from and joined back into the caller's stream
     if (e == hipSuccess) e = hipEventRecord(q->fork, user);
-    int cur_bin = -1;
+    bool forked[2] = {false, false};
     for (size_t li = 0; li < plan.size() && e == hipSuccess && rc == MATINV_OK; ++li) {
         const Launch &L = plan[li];
-        hipStream_t s = q->streams[L.bin];
-        if (L.bin != cur_bin) {
+        hipStream_t s = stream_of(L.bin);
+        if (!forked[slot_of(L.bin)]) {
             e = hipStreamWaitEvent(s, q->fork, 0);
-            cur_bin = L.bin;
+            forked[slot_of(L.bin)] = true;
             if (e != hipSuccess) break;
         }
         auto segcopy = [&](size_t seg0, size_t segs, size_t typical_bytes) {
@@ -344,13 +352,13 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
         if (L.out_segs) e = segcopy(L.out_seg0, L.out_segs, 0);
         if (e == hipSuccess && L.staging) e = hipFreeAsync(L.staging, s);
     }
-    for (size_t b = 0; b < q->bins.size(); ++b) {
-        if (q->q[b].empty()) continue;
-        hipError_t e2 = hipEventRecord(q->done[b], q->streams[b]);
-        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(user, q->done[b], 0);
+    for (int slot = 0; slot < 2; ++slot) {
+        if (!forked[slot]) continue;
+        hipError_t e2 = hipEventRecord(q->done[slot], q->streams[slot]);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(user, q->done[slot], 0);
         if (e == hipSuccess) e = e2;
-        q->q[b].clear();
     }
+    for (size_t b = 0; b < q->bins.size(); ++b) q->q[b].clear();
     if (dev_tab) {
         hipError_t e2 = hipFreeAsync(dev_tab, user);  // after the join: every launch that reads it has been ordered before
         if (e == hipSuccess) e = e2;
