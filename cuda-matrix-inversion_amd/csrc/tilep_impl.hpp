@@ -27,6 +27,8 @@
 // need row exchanges (the reference swaps only on an exactly zero diagonal, :19-35; tests/square_5_*.mats are such inputs).
 #pragma once
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "tile_common.hpp"
 #include "wave_util.hpp"
