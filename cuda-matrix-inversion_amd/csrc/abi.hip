@@ -131,7 +131,7 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
     case MATINV_KERNEL_TILE:
         if (algo == MATINV_ALGO_CHOLESKY) {
             if (!spd_tile_supports<T>(n) || chol_phases != 7)
-                return fail(MATINV_ERR_UNSUPPORTED, "tile family serves the full SPD inverse with n <= 128 (f64) / 64 (f32) only (n=%d)", n);
+                return fail(MATINV_ERR_UNSUPPORTED, "tile family serves the full SPD inverse with n <= 192 (f64) / 256 (f32) only (n=%d)", n);
             e = launch_spd_tile<T>(n, A, X, batch, dInfo, stream);
             break;
         }
@@ -426,7 +426,7 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             return MATINV_OK;
         }
     }
-    if (tile4_supports(n)) {
+    if (tile4_supports(n) || (n > 128 && n <= (sizeof(T) == 8 ? 192 : 208))) {  // tile4_impl.hpp: gp_tile4_wide_supports
         static const bool use_tile4 = []() {
             const char *s = getenv("MATINV_GP_TILE4");  // A/B switch for profiling; default on
             return !(s && *s == '0');

@@ -129,6 +129,7 @@ bool tile_family_supports(int n);
 // four-wave variant of the tile family, 64 < n <= 128, f64 and f32 (tile4_kernels.hip); the spd entry is the same
 // kernel with lower-triangle loads and positivity-checked pivots (the Cholesky contract)
 bool tile4_supports(int n);
+bool tile4_wide_supports(bool f64, int n);  // SPD sweep and fused pipeline only: 128 < n <= 192 (f64) / 256 (f32)
 template <class T>
 hipError_t launch_gj_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 template <class T>

@@ -46,6 +46,10 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                                               int *work_count, int *work_list, T *panel, GpArgs<T> gp = GpArgs<T>())
 {
     static_assert(!GP || SPD, "the fused pipeline runs the SPD sweep");
+    static_assert(NT <= 8 || SPD, "more than 8 x 8 tiles: SPD sweep only (a rejected general matrix would need a pivoting kernel of that size)");
+    // NT > 8: no kernel behind this one serves every such n, so a matrix that is not positive definite is finished here:
+    // info = the column of the first non-positive pivot + 1 (the Cholesky contract), output NaN-filled
+    constexpr bool SELF = NT > 8;
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
     constexpr int N = 16 * NT;
@@ -90,8 +94,8 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                 }
             }
         unsigned long long bad = 0;
+        int badinfo = 0;
         T aop[NT], bop[NC];
-
         // Look-ahead pipeline with ONE workgroup barrier per block step (the panel is double buffered in LDS):
         //   every wave updates its local column jo_n first (for the next owner that is the column holding the next
         //   pivot columns); the next owner stages them; barrier; the other local column is updated while every wave
@@ -110,6 +114,7 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
         __syncthreads();
         {
             PanelSolve<NT, SPD, T> ps0;
+            if (SELF) ps0.binfo = &badinfo;
 #pragma unroll
             for (int s0 = 0; s0 < PanelSolve<NT, SPD, T>::NSTAGE; ++s0) ps0.stage(s0, panel, 0, q, c, aop, bad);
         }
@@ -181,6 +186,7 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                 constexpr int NB = NT * (NC - 1);
                 T aop_next[NT];
                 PanelSolve<NT, SPD, T> ps;
+                if (SELF) ps.binfo = &badinfo;
                 int count = 0, ev = 0;
                 auto run_events = [&](bool flush) {
 #pragma unroll
@@ -254,6 +260,10 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                 for (int i = 0; i < T4_WAVES; ++i) sum += panel[i];
                 gp.out[mat] = gp.d ? sum : gp.e[mat] - sum;
             }
+            if (SELF && bad != 0 && threadIdx.x == 0) {
+                gp.out[mat] = nan_of<T>();
+                if (info) info[mat] = badinfo;
+            }
             __syncthreads();  // the next matrix stages its first panel into the same buffer
         }
         if (GP && bad == 0) {
@@ -273,6 +283,13 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                     }
                 }
             if (info && threadIdx.x == 0) info[mat] = 0;
+        } else if (SELF) {
+            if (!GP) {
+                // (a plain strided fill: written over the tile structure, the 16 NT address offsets of this rare path are
+                // hoisted out of the batch loop by LICM and the whole kernel spills -- 4 700 VGPR spills at 12 x 12 tiles)
+                for (unsigned e = threadIdx.x; e < (unsigned)(n * n); e += 64u * T4_WAVES) X[e] = nan_of<T>();
+                if (info && threadIdx.x == 0) info[mat] = badinfo;
+            }
         } else if (threadIdx.x == 0) {
             const int slot = atomicAdd(work_count, 1);
             work_list[slot] = (int)mat;
@@ -282,7 +299,7 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
 
 // SPD = the Cholesky entry point for 64 < n <= 128 (see gj_tile4_body).
 template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
-__global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
+__global__ __launch_bounds__(64 * T4_WAVES, T4_WAVES > 4 ? 1 : ((NT <= 4) ? 3 : 2)) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
                                                                        int *info, int n_rt, unsigned batch,
                                                                        int *work_count, int *work_list)
 {
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(64 * T4_WAVES, (NT <= 4) ? 3 : 2) void matinv_gj_ti
 }
 // fp32 (the reference's DataType; its benchmark sweep goes up to n = 128): 16 tiles x 4 VGPRs per wave
 template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
-__global__ __launch_bounds__(64 * T4_WAVES, (T4_WAVES <= 2 ? 2 : 3)) void matinv_gj_tile4_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
+__global__ __launch_bounds__(64 * T4_WAVES, T4_WAVES > 4 ? 1 : (T4_WAVES <= 2 ? 2 : 3)) void matinv_gj_tile4_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
                                                                        int n_rt, unsigned batch, int *work_count, int *work_list)
 {
     __shared__ __attribute__((aligned(16))) float panel[2 * 16 * NT * 4];
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(64 * T4_WAVES, (T4_WAVES <= 2 ? 2 : 3)) void matinv
 
 // fused mean / variance, 64 < n <= 128 (run-time n only: one instantiation per NT and dtype)
 template <int NT, int W>
-__global__ __launch_bounds__(64 * W, 2) void matinv_gp_tile4_f64(const double *As, const double *Bs, const double *Cs, const double *Ds,
+__global__ __launch_bounds__(64 * W, W > 4 ? 1 : 2) void matinv_gp_tile4_f64(const double *As, const double *Bs, const double *Cs, const double *Ds,
                                                              const double *Es, double *out, int *info, int n_rt, unsigned batch,
                                                              int *work_count, int *work_list)
 {
@@ -311,7 +328,7 @@ __global__ __launch_bounds__(64 * W, 2) void matinv_gp_tile4_f64(const double *A
                                                    GpArgs<double>{As, Cs, Ds, Es, out});
 }
 template <int NT, int W>
-__global__ __launch_bounds__(64 * W, (W <= 2 ? 2 : 3)) void matinv_gp_tile4_f32(const float *As, const float *Bs, const float *Cs, const float *Ds,
+__global__ __launch_bounds__(64 * W, W > 4 ? 1 : (W <= 2 ? 2 : 3)) void matinv_gp_tile4_f32(const float *As, const float *Bs, const float *Cs, const float *Ds,
                                                              const float *Es, float *out, int *info, int n_rt, unsigned batch,
                                                              int *work_count, int *work_list)
 {
@@ -328,12 +345,18 @@ __global__ __launch_bounds__(64 * W, (W <= 2 ? 2 : 3)) void matinv_gp_tile4_f32(
 //        n=112: - / 1.90e7 / 1.75e7 / 1.73e7        n=128: - / 1.40e7 / 1.11e7 / 1.45e7
 // Every wave repeats the panel solve, so the fewest waves whose tile columns still fit the register file win (f32 n=96 on one
 // wave spills in the SPD / pipeline variants -- 2.6e7 and 1.9e7 against 2.7e7 and 2.2e7 on four -- so it takes two).
-constexpr int t4_waves(bool f64, int nt) { return f64 ? (nt <= 6 ? 2 : 4) : (nt <= 5 ? 1 : (nt <= 7 ? 2 : 4)); }
+// Beyond 8 tiles per dimension (r02: the Cholesky entry point and the fused pipeline up to n = 192 in f64, 256 in f32) every
+// wavefront holds ONE tile column: NT wavefronts per matrix, one workgroup per CU. An f64 matrix of 12 x 12 tiles is 1 152 of
+// the CU's 2 048 VGPRs per lane; 13 x 13 no longer leaves room for the working registers of 13 waves.
+constexpr int t4_waves(bool f64, int nt) { return nt > 8 ? nt : (f64 ? (nt <= 6 ? 2 : 4) : (nt <= 5 ? 1 : (nt <= 7 ? 2 : 4))); }
+constexpr int t4_wide_limit(bool f64) { return f64 ? 192 : 256; }
+// the fused pipeline in f32 stops at 13 x 13 tiles: at 256 the blocked path is faster (1.4e6 items/s against 1.0e6)
+constexpr bool gp_tile4_wide_supports(bool f64, int n) { return n > 128 && n <= (f64 ? 192 : 208); }
 
 template <class T, bool SPD>
 static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
-    if (!tile4_supports(n)) return hipErrorInvalidValue;
+    if (!(tile4_supports(n) || (SPD && n > 128 && n <= t4_wide_limit(sizeof(T) == 8)))) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     // Gauss-Jordan: general batches go straight to the four-wave PIVOTING kernel once a natural-order launch of this size
     // has seen most of its matrices rejected (tile_kernels.inc "natural order or pivot search?")
@@ -347,8 +370,17 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
         return e;
     }
     const int nt = (n + 15) / 16;
-    const unsigned grid = (unsigned)(batch < 256u * 3u * tile_grid_rounds() ? batch : 256u * 3u * tile_grid_rounds());
+    const unsigned resident = nt > 8 ? 256u : 256u * 3u;  // NT wavefronts per matrix: one workgroup per CU
+    const unsigned grid = (unsigned)(batch < resident * tile_grid_rounds() ? batch : resident * tile_grid_rounds());
     const unsigned b = (unsigned)batch;
+// more than 8 x 8 tiles: run-time n only, SPD only, f64 up to 12 x 12
+#define T4_WIDE(NT_)                                                                                                  \
+    if constexpr (SPD && (sizeof(T) == 4 || NT_ <= 12)) {                                                             \
+        if constexpr (sizeof(T) == 8)                                                                                 \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 1); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 1); \
+    }
 #define T4_LAUNCH(NT_)                                                                                                \
     if constexpr (sizeof(T) == 8) {                                                                                   \
         if (n == 16 * NT_)                                                                                            \
@@ -365,11 +397,20 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     case 5: T4_LAUNCH(5) break;
     case 6: T4_LAUNCH(6) break;
     case 7: T4_LAUNCH(7) break;
-    default: T4_LAUNCH(8) break;
+    case 8: T4_LAUNCH(8) break;
+    case 9: T4_WIDE(9) break;
+    case 10: T4_WIDE(10) break;
+    case 11: T4_WIDE(11) break;
+    case 12: T4_WIDE(12) break;
+    case 13: T4_WIDE(13) break;
+    case 14: T4_WIDE(14) break;
+    case 15: T4_WIDE(15) break;
+    default: T4_WIDE(16) break;
     }
 #undef T4_LAUNCH
+#undef T4_WIDE
     e = hipGetLastError();
-    if (e == hipSuccess)
+    if (e == hipSuccess && nt <= 8)  // beyond 8 x 8 tiles the kernel finishes its rejects itself
         e = SPD ? launch_chol_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream)
                 : launch_gj_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream);
     if (e == hipSuccess && !SPD) e = launch_hint_store(ws, tile_policy_record(sizeof(T) == 8, nt, batch), stream);
@@ -391,7 +432,7 @@ template <class T>
 hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
                            int *info, hipStream_t stream)
 {
-    if (!tile4_supports(n)) return hipErrorInvalidValue;
+    if (!(tile4_supports(n) || gp_tile4_wide_supports(sizeof(T) == 8, n))) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -402,7 +443,7 @@ hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T
         return e;
     }
     const int nt = (n + 15) / 16;
-    const unsigned occ = sizeof(T) == 8 ? 2u : 3u;
+    const unsigned occ = nt > 8 ? 1u : (sizeof(T) == 8 ? 2u : 3u);
     const unsigned grid = (unsigned)(batch < 256u * occ * tile_grid_rounds() ? batch : 256u * occ * tile_grid_rounds());
     const unsigned b = (unsigned)batch;
 #define GP4_LAUNCH(NT_)                                                                                               \
@@ -414,11 +455,25 @@ hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T
     case 5: GP4_LAUNCH(5) break;
     case 6: GP4_LAUNCH(6) break;
     case 7: GP4_LAUNCH(7) break;
-    default: GP4_LAUNCH(8) break;
+    case 8: GP4_LAUNCH(8) break;
+    case 9: GP4_LAUNCH(9) break;
+    case 10: GP4_LAUNCH(10) break;
+    case 11: GP4_LAUNCH(11) break;
+    case 12: GP4_LAUNCH(12) break;
+    default:
+        if constexpr (sizeof(T) == 4) {
+            switch (nt) {
+            case 13: GP4_LAUNCH(13) break;
+            case 14: GP4_LAUNCH(14) break;
+            case 15: GP4_LAUNCH(15) break;
+            default: GP4_LAUNCH(16) break;
+            }
+        }
+        break;
     }
 #undef GP4_LAUNCH
     e = hipGetLastError();
-    if (e == hipSuccess) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
+    if (e == hipSuccess && nt <= 8) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
 }

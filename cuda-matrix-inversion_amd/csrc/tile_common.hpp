@@ -108,6 +108,37 @@ __device__ __forceinline__ void note_nonpositive(unsigned long long &bad, float 
     asm volatile("v_cmp_ngt_f32_e64 vcc, %1, 0\n\ts_or_b64 %0, %0, vcc" : "+s"(bad) : "v"(v) : "vcc");
 }
 
+// the same, and binfo = val at the FIRST pivot that fails (binfo stays 0 while every pivot was positive). All in scalar
+// instructions inside one asm block: written as a C++ select on `bad` hipcc spills hundreds of SGPRs in the 12 x 12 tile kernel.
+__device__ __forceinline__ void note_nonpositive_first(unsigned long long &bad, int &binfo, double v, int val)
+{
+    int tmp;
+    asm volatile("v_cmp_ngt_f64_e64 vcc, %[v], 0\n\t"
+                 "s_cmp_eq_u64 %[bad], 0\n\t"
+                 "s_cselect_b32 %[tmp], %[val], 0\n\t"
+                 "s_cmp_lg_u64 vcc, 0\n\t"
+                 "s_cselect_b32 %[tmp], %[tmp], 0\n\t"
+                 "s_or_b32 %[binfo], %[binfo], %[tmp]\n\t"
+                 "s_or_b64 %[bad], %[bad], vcc"
+                 : [bad] "+s"(bad), [binfo] "+s"(binfo), [tmp] "=&s"(tmp)
+                 : [v] "v"(v), [val] "s"(val)
+                 : "vcc", "scc");
+}
+__device__ __forceinline__ void note_nonpositive_first(unsigned long long &bad, int &binfo, float v, int val)
+{
+    int tmp;
+    asm volatile("v_cmp_ngt_f32_e64 vcc, %[v], 0\n\t"
+                 "s_cmp_eq_u64 %[bad], 0\n\t"
+                 "s_cselect_b32 %[tmp], %[val], 0\n\t"
+                 "s_cmp_lg_u64 vcc, 0\n\t"
+                 "s_cselect_b32 %[tmp], %[tmp], 0\n\t"
+                 "s_or_b32 %[binfo], %[binfo], %[tmp]\n\t"
+                 "s_or_b64 %[bad], %[bad], vcc"
+                 : [bad] "+s"(bad), [binfo] "+s"(binfo), [tmp] "=&s"(tmp)
+                 : [v] "v"(v), [val] "s"(val)
+                 : "vcc", "scc");
+}
+
 // SPD = true: symmetric blocked sweep for SPD input (see matinv_spd_tile_f64). Same arithmetic for D^-1 and Aop; the
 // acceptance test becomes "all four pivots of D positive" (they are the squares of the Cholesky diagonal), and the
 // stage of tile row ti also returns bsym[ti] = P[16ti + c][q], the B operand by symmetry (W[K, J] = W[J, K]^T).
@@ -115,6 +146,7 @@ template <int NT, bool SPD = false, class T = double>
 struct PanelSolve {
     typedef TileGeo<T> G;
     static constexpr int NSTAGE = 6 + NT;
+    int *binfo = nullptr;  // SPD: when set, *binfo becomes (column of the FIRST non-positive pivot) + 1 (scalar selects only)
     T d[4][4];
     T r0, r1, r2, r3, l10, l20, l30, l21, l31, l32, u11, u12, u13, u22, u23, u33;
     T a21, a22, a23, a31, a32, a33, b32, b33, y0, y1, y2, y3, x0, x1, x2, x3;
@@ -156,8 +188,15 @@ struct PanelSolve {
         } else if (s == 3) {
             r3 = fast_rcp(u33);
             if (SPD) {
-                note_nonpositive(bad, d[0][0]), note_nonpositive(bad, u11);
-                note_nonpositive(bad, u22), note_nonpositive(bad, u33);
+                if (binfo) {
+                    note_nonpositive_first(bad, *binfo, d[0][0], 16 * tK + G::pcol(rK, 0) + 1);
+                    note_nonpositive_first(bad, *binfo, u11, 16 * tK + G::pcol(rK, 1) + 1);
+                    note_nonpositive_first(bad, *binfo, u22, 16 * tK + G::pcol(rK, 2) + 1);
+                    note_nonpositive_first(bad, *binfo, u33, 16 * tK + G::pcol(rK, 3) + 1);
+                } else {
+                    note_nonpositive(bad, d[0][0]), note_nonpositive(bad, u11);
+                    note_nonpositive(bad, u22), note_nonpositive(bad, u33);
+                }
             } else {
                 note_fail(bad, l10), note_fail(bad, l20), note_fail(bad, l30);
                 note_fail(bad, l21), note_fail(bad, l31), note_fail(bad, l32);

@@ -45,7 +45,12 @@ def test_kernel_selection_is_pure_host_logic():
         assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, n).startswith("matinv_")
         assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, n) == (api.KERNEL_ROWLANE if n <= 16 else api.KERNEL_TILE)
         assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, n) == (api.KERNEL_ROWLANE if n <= 16 else api.KERNEL_TILE)
-    assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, 129) == api.KERNEL_BLOCKED
+    assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, 129) == api.KERNEL_TILE   # one wavefront per tile column up to 192 / 256
+    assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, 192) == api.KERNEL_TILE
+    assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, 193) == api.KERNEL_BLOCKED
+    assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, 256) == api.KERNEL_TILE
+    assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, 257) == api.KERNEL_BLOCKED
+    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 192) == "matinv_gj_tile4_f64<12, false, 12, true>"
     assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, 1024) == api.KERNEL_BLOCKED
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 128) == "matinv_gj_tile4_f32<8, true, 4, false>"
     assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 100) == "matinv_gj_tile4_f64<7, false, 4, true>"

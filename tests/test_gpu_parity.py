@@ -249,9 +249,13 @@ def test_large_n_global_family(n, batch):
         api.inverse_batched(torch.zeros(4, dtype=torch.float64, device="cuda"), 1025, GJ, batch=0 + 1)
 
 
-@pytest.mark.parametrize("n,batch,dtype", [(129, 9, "f64"), (200, 5, "f64"), (333, 3, "f64"), (512, 2, "f32"), (1000, 2, "f32")])
-def test_cholesky_large_n_blocked(n, batch, dtype):
-    """SPD inverse beyond the four-wave kernel: blocked Cholesky with an identity border + symmetric product
+@pytest.mark.parametrize("forced", [False, True])
+@pytest.mark.parametrize("n,batch,dtype", [(129, 9, "f64"), (144, 6, "f64"), (177, 5, "f64"), (192, 5, "f64"), (200, 5, "f64"),
+                                           (333, 3, "f64"), (130, 7, "f32"), (200, 5, "f32"), (241, 4, "f32"), (256, 4, "f32"),
+                                           (512, 2, "f32"), (1000, 2, "f32")])
+def test_cholesky_large_n_blocked(n, batch, dtype, forced):
+    """SPD inverse beyond the four-wave kernel: up to 12 x 12 (f64) / 16 x 16 (f32) tiles one wavefront per tile column
+    (tile4_impl.hpp, r02), beyond that -- or forced -- blocked Cholesky with an identity border + symmetric product
     (blocked_gp_kernels.hip). Ragged panels / tiles, garbage in the strict upper triangle (must not be read), an item that
     is not positive definite (info = failing column, NaN result, neighbours untouched), both precisions."""
     a = spd_batch(n, batch, seed=40 + n)
@@ -262,15 +266,21 @@ def test_cholesky_large_n_blocked(n, batch, dtype):
     bad = batch - 1
     dirty[bad, n // 3, n // 3] = -1.0                   # pivot n/3 turns negative
     np_t = np.float64 if dtype == "f64" else np.float32
-    assert api.select_kernel(CH, api.F64 if dtype == "f64" else api.F32, n) == api.KERNEL_BLOCKED
-    got, info = gpu_inverse(dirty.reshape(-1).astype(np_t), n, CH, want_info=True)
+    wide = n <= (192 if dtype == "f64" else 256)
+    assert api.select_kernel(CH, api.F64 if dtype == "f64" else api.F32, n) == (api.KERNEL_TILE if wide else api.KERNEL_BLOCKED)
+    if forced and not wide:
+        pytest.skip("the automatic path is the blocked one already")
+    got, info = gpu_inverse(dirty.reshape(-1).astype(np_t), n, CH, api.KERNEL_BLOCKED if forced else api.KERNEL_AUTO, want_info=True)
     got = got.astype(np.float64)
     assert info.tolist() == [0] * (batch - 1) + [n // 3 + 1]
     assert np.isnan(as_mats(got, n)[bad]).all()
     g, w_ = as_mats(got, n)[:bad], as_mats(want, n)[:bad]
     err = (np.linalg.norm((g - w_).reshape(bad, -1), axis=1) / np.linalg.norm(w_.reshape(bad, -1), axis=1)).max()
     assert err < (1e-12 if dtype == "f64" else 2e-5)
-    assert np.array_equal(g, g.transpose(0, 2, 1))     # mirrored on write: exactly symmetric
+    if forced or not wide:
+        assert np.array_equal(g, g.transpose(0, 2, 1))     # blocked path: mirrored on write, exactly symmetric
+    else:
+        assert np.abs(g - g.transpose(0, 2, 1)).max() < (1e-14 if dtype == "f64" else 1e-6) * np.abs(g).max()
 
 
 @pytest.mark.parametrize("n,batch,dtype", [(138, 6, "f64"), (200, 4, "f64"), (333, 3, "f64"), (512, 2, "f32"), (1000, 2, "f32"), (1024, 1, "f64")])
@@ -319,8 +329,7 @@ for algo, oalgo, a in ((api.ALGO_GAUSS_JORDAN, oracle.ALGO_GJ_PIVOT, general_bat
                        (api.ALGO_CHOLESKY, oracle.ALGO_CHOLESKY, spd_batch(n, batch, seed=2))):
     want, _ = oracle.inverse_batched(a, n, oalgo)
     info = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
-    got = api.inverse_batched(torch.from_numpy(a).cuda(), n, algo, batch=batch, info=info).cpu().numpy()
-    assert api.select_kernel(algo, api.F64, n) == api.KERNEL_BLOCKED
+    got = api.inverse_batched(torch.from_numpy(a).cuda(), n, algo, batch=batch, info=info, kernel=api.KERNEL_BLOCKED).cpu().numpy()
     assert not info.cpu().numpy().any()
     cond = max(np.linalg.cond(m) for m in a.reshape(batch, n, n))
     assert rel_err(got, want, n) < max(1e-10, 1e-15 * cond * n), algo
