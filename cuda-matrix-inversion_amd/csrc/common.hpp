@@ -173,6 +173,17 @@ template <>
 hipError_t launch_gj_tilep4<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
 template <>
 hipError_t launch_gj_tilep4<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+hipError_t launch_gj_tilep4_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count, const int *in_list,
+                                     int *bad_count, int *bad_list, int *info, hipStream_t stream, int *hint_out);
+template <>
+hipError_t launch_gj_tilep4_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
+                                             const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
+                                             int *hint_out);
+template <>
+hipError_t launch_gj_tilep4_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
+                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
+                                            int *hint_out);
 const char *name_gj_tilep4(bool f64, int n);
 // second-generation natural-order tile kernel, n <= 64 (tilen_kernels.hip): enqueue only, the caller owns the work list
 template <class T>
@@ -186,8 +197,6 @@ hipError_t enqueue_gj_tilen<float>(int n, BatchRef<const float> A, BatchRef<floa
                                    int *work_count, int *work_list);
 bool tile_natural_old();  // MATINV_TILE_NATURAL=old: the r01 kernel of tile_kernels.inc (A/B measurements)
 const char *name_gj_tilen(bool f64, int n);
-// after a natural-order launch whose rejects do not pass through the pivoting work-list kernel: *hint_out = *dev_count
-hipError_t launch_hint_store(const int *dev_count, int *hint_out, hipStream_t stream);
 // Adaptive choice between the natural-order (verified) tile kernel and the pivoting one (tile_kernels.hip): see gj_tile_policy
 struct TileStats {
     unsigned long long natural_launches, pivot_launches, last_rejected, last_batch;

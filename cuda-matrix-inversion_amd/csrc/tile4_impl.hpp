@@ -178,9 +178,7 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                 for (int ti = 0; ti < NT; ++ti)
                     acc[ti][jn] = G::mfma(aop[ti], bop[jn], acc[ti][jn]);
                 stage_panel(kb + 1);
-#ifndef TILE_DBG_NO_BARRIER
                 __syncthreads();
-#endif
                 const T *pnext = panel + ((kb + 1) & 1) * (N * 4);
                 constexpr int NS = PanelSolve<NT, SPD, T>::NSTAGE;
                 constexpr int NB = NT * (NC - 1);
@@ -194,11 +192,7 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                         const int thr = (NB * e) / NS;
                         if (e == ev && (flush || thr <= count)) {
                             __builtin_amdgcn_sched_barrier(0);
-#ifndef TILE_DBG_NO_PANEL
                             ps.stage(e, pnext, kb + 1, q, c, aop_next, bad);
-#else
-                            if (e >= 6) aop_next[e - 6] = aop[e - 6] * (T)0.5 + pnext[(16 * (e - 6) + c) * 4];
-#endif
                             __builtin_amdgcn_sched_barrier(0);
                             ++ev;
                         }
@@ -361,10 +355,11 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     // Gauss-Jordan: general batches go straight to the four-wave PIVOTING kernel once a natural-order launch of this size
     // has seen most of its matrices rejected (tile_kernels.inc "natural order or pivot search?")
     if (!SPD && tile_policy_use_pivot(sizeof(T) == 8, (n + 15) / 16)) return launch_gj_tilep4<T>(n, A, X, batch, info, stream);
+    // [0], [1] = counts; [2 .. batch+2) = rejected matrices; [batch+2 ..) = (Gauss-Jordan) the singular ones among them
     int *ws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (2 * batch + 2) * sizeof(int), stream);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    e = hipMemsetAsync(ws, 0, 2 * sizeof(int), stream);
     if (e != hipSuccess) {
         (void)hipFreeAsync(ws, stream);
         return e;
@@ -377,21 +372,21 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 #define T4_WIDE(NT_)                                                                                                  \
     if constexpr (SPD && (sizeof(T) == 4 || NT_ <= 12)) {                                                             \
         if constexpr (sizeof(T) == 8)                                                                                 \
-            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 1); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 2); \
         else                                                                                                          \
-            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 1); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 2); \
     }
 #define T4_LAUNCH(NT_)                                                                                                \
     if constexpr (sizeof(T) == 8) {                                                                                   \
         if (n == 16 * NT_)                                                                                            \
-            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 1); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2); \
         else                                                                                                          \
-            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 1); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2); \
     } else {                                                                                                          \
         if (n == 16 * NT_)                                                                                            \
-            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, true, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 1); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, true, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2); \
         else                                                                                                          \
-            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 1); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2); \
     }
     switch (nt) {
     case 5: T4_LAUNCH(5) break;
@@ -410,10 +405,12 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 #undef T4_LAUNCH
 #undef T4_WIDE
     e = hipGetLastError();
-    if (e == hipSuccess && nt <= 8)  // beyond 8 x 8 tiles the kernel finishes its rejects itself
-        e = SPD ? launch_chol_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream)
-                : launch_gj_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream);
-    if (e == hipSuccess && !SPD) e = launch_hint_store(ws, tile_policy_record(sizeof(T) == 8, nt, batch), stream);
+    if (e == hipSuccess && nt <= 8) {  // beyond 8 x 8 tiles the kernel finishes its rejects itself
+        if (SPD) e = launch_chol_lds_worklist<T>(n, A, X, ws, ws + 2, info, stream);
+        else  // rejected = needs row exchanges: the four-wave PIVOTING kernel, in the same stream
+            e = launch_gj_tilep4_worklist<T>(n, A, X, batch, ws, ws + 2, ws + 1, ws + 2 + batch, info, stream,
+                                             tile_policy_record(sizeof(T) == 8, nt, batch));
+    }
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
 }

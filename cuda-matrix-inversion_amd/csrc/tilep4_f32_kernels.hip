@@ -9,4 +9,12 @@ hipError_t launch_gj_tilep4<float>(int n, BatchRef<const float> A, BatchRef<floa
     return launch_tilep4<float>(n, A, X, batch, info, stream);
 }
 
+template <>
+hipError_t launch_gj_tilep4_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
+                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
+                                            int *hint_out)
+{
+    return launch_tilep4_worklist<float>(n, A, X, batch, in_count, in_list, bad_count, bad_list, info, stream, hint_out);
+}
+
 }  // namespace matinv

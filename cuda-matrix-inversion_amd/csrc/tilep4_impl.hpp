@@ -72,7 +72,8 @@ __device__ __forceinline__ void gather_zero_tile_row2(typename TileGeo<T>::vec4 
 
 template <class T, int NT, bool FULL>
 __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
-                                               T *panel2, T *bball, unsigned char *tab, int *bad_count, int *bad_list)
+                                               T *panel2, T *bball, unsigned char *tab, int *bad_count, int *bad_list,
+                                               const int *in_count, const int *in_list, int *hint_out)
 {
     static_assert(NT >= 5 && NT <= 8, "four wavefronts serve 64 < n <= 128");
     typedef TileGeo<T> G;
@@ -86,7 +87,12 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
     typedef __attribute__((address_space(3))) T *lds_ptr;
     const unsigned bb_lane = (unsigned)(size_t)(lds_ptr)(bbuf + (l & 15));
 
-    for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
+    // work-list form (the matrices the natural-order four-wave kernel rejected): in_list[0 .. *in_count); its length goes
+    // back to the launcher's natural / pivot guess through pinned host memory (see tilep_impl.hpp)
+    const unsigned todo = in_count ? (unsigned)*in_count : batch;
+    if (hint_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint_out, (int)todo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (unsigned item = blockIdx.x; item < todo; item += gridDim.x) {
+        const unsigned mat = in_list ? (unsigned)in_list[item] : item;
         const T *A = Ain.at_uniform(mat);
         T *X = Xout.at_uniform(mat);
         int n = FULL ? N : n_rt;
@@ -317,22 +323,55 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
 
 template <int NT, bool FULL>
 __global__ __launch_bounds__(256, 2) void matinv_gj_tilep4_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
-                                                              unsigned batch, int *bad_count, int *bad_list)
+                                                              unsigned batch, int *bad_count, int *bad_list, const int *in_count,
+                                                              const int *in_list, int *hint_out)
 {
     __shared__ __attribute__((aligned(16))) double panel2[2 * 16 * NT * 4];
     __shared__ __attribute__((aligned(16))) double bball[4 * 4 * 32];
     __shared__ unsigned char tab[256];
-    gj_tilep4_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list);
+    gj_tilep4_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out);
 }
 
 template <int NT, bool FULL>
 __global__ __launch_bounds__(256, 3) void matinv_gj_tilep4_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n_rt,
-                                                              unsigned batch, int *bad_count, int *bad_list)
+                                                              unsigned batch, int *bad_count, int *bad_list, const int *in_count,
+                                                              const int *in_list, int *hint_out)
 {
     __shared__ __attribute__((aligned(16))) float panel2[2 * 16 * NT * 4];
     __shared__ __attribute__((aligned(16))) float bball[4 * 4 * 32];
     __shared__ unsigned char tab[256];
-    gj_tilep4_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list);
+    gj_tilep4_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out);
+}
+
+template <class T>
+static hipError_t enqueue_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *bad_count,
+                                 int *bad_list, const int *in_count, const int *in_list, int *hint_out)
+{
+    const int nt = (n + 15) / 16;
+    unsigned cap = 256u * 3u * tile_grid_rounds();
+    if (in_list) cap = 256u * 3u;  // usually empty: one round of resident workgroups
+    const unsigned grid = (unsigned)(batch < cap ? batch : cap);
+    const unsigned b = (unsigned)batch;
+#define TP4_LAUNCH(NT_)                                                                                                \
+    if constexpr (sizeof(T) == 8) {                                                                                    \
+        if (n == 16 * NT_)                                                                                             \
+            hipLaunchKernelGGL((matinv_gj_tilep4_f64<NT_, true>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((matinv_gj_tilep4_f64<NT_, false>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
+    } else {                                                                                                           \
+        if (n == 16 * NT_)                                                                                             \
+            hipLaunchKernelGGL((matinv_gj_tilep4_f32<NT_, true>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((matinv_gj_tilep4_f32<NT_, false>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
+    }
+    switch (nt) {
+    case 5: TP4_LAUNCH(5) break;
+    case 6: TP4_LAUNCH(6) break;
+    case 7: TP4_LAUNCH(7) break;
+    default: TP4_LAUNCH(8) break;
+    }
+#undef TP4_LAUNCH
+    return hipGetLastError();
 }
 
 template <class T>
@@ -348,33 +387,23 @@ static hipError_t launch_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_
         (void)hipFreeAsync(ws, stream);
         return e;
     }
-    const int nt = (n + 15) / 16;
-    const unsigned cap = 256u * 3u * tile_grid_rounds();
-    const unsigned grid = (unsigned)(batch < cap ? batch : cap);
-    const unsigned b = (unsigned)batch;
-#define TP4_LAUNCH(NT_)                                                                                                \
-    if constexpr (sizeof(T) == 8) {                                                                                    \
-        if (n == 16 * NT_)                                                                                             \
-            hipLaunchKernelGGL((matinv_gj_tilep4_f64<NT_, true>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
-        else                                                                                                           \
-            hipLaunchKernelGGL((matinv_gj_tilep4_f64<NT_, false>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
-    } else {                                                                                                           \
-        if (n == 16 * NT_)                                                                                             \
-            hipLaunchKernelGGL((matinv_gj_tilep4_f32<NT_, true>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
-        else                                                                                                           \
-            hipLaunchKernelGGL((matinv_gj_tilep4_f32<NT_, false>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, ws, ws + 1); \
-    }
-    switch (nt) {
-    case 5: TP4_LAUNCH(5) break;
-    case 6: TP4_LAUNCH(6) break;
-    case 7: TP4_LAUNCH(7) break;
-    default: TP4_LAUNCH(8) break;
-    }
-#undef TP4_LAUNCH
-    e = hipGetLastError();
+    e = enqueue_tilep4<T>(n, A, X, batch, info, stream, ws, ws + 1, nullptr, nullptr, nullptr);
+    // singular input only: the pivoted LDS kernel reports the exact step and NaN-fills the output
     if (e == hipSuccess) e = launch_gj_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream);
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
+}
+
+// the matrices the natural-order four-wave kernel rejected: (in_count, in_list); the singular ones among them go on to the LDS
+// kernel through (bad_count, bad_list), zeroed by the caller
+template <class T>
+static hipError_t launch_tilep4_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count,
+                                         const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
+                                         int *hint_out)
+{
+    hipError_t e = enqueue_tilep4<T>(n, A, X, batch, info, stream, bad_count, bad_list, in_count, in_list, hint_out);
+    if (e == hipSuccess) e = launch_gj_lds_worklist<T>(n, A, X, bad_count, bad_list, info, stream);
+    return e;
 }
 
 }  // namespace matinv

@@ -9,6 +9,14 @@ hipError_t launch_gj_tilep4<double>(int n, BatchRef<const double> A, BatchRef<do
     return launch_tilep4<double>(n, A, X, batch, info, stream);
 }
 
+template <>
+hipError_t launch_gj_tilep4_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
+                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
+                                            int *hint_out)
+{
+    return launch_tilep4_worklist<double>(n, A, X, batch, in_count, in_list, bad_count, bad_list, info, stream, hint_out);
+}
+
 const char *name_gj_tilep4(bool f64, int n)
 {
     static thread_local char buf[48];
