@@ -84,6 +84,7 @@ int select_auto(int algo, int n)
     if (algo == MATINV_ALGO_GAUSS_JORDAN) {
         if (rowlane_family_supports<T>(n)) return MATINV_KERNEL_ROWLANE;
         if (tile_family_supports<T>(n)) return MATINV_KERNEL_TILE;
+        if (tilepw_supports(sizeof(T) == 8, n)) return MATINV_KERNEL_TILEP;  // one wavefront per tile column, pivoting
         if (blocked_gj_supports(n)) return MATINV_KERNEL_BLOCKED;  // beyond n = 128 it beats the LDS kernel at every size measured
     } else if (rowlane_family_supports<T>(n)) {
         return MATINV_KERNEL_ROWLANE;  // several SPD matrices per wavefront
@@ -156,9 +157,10 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
         e = launch_chol_blocked<T>(n, A, X, batch, dInfo, stream);
         break;
     case MATINV_KERNEL_TILEP:
-        if (algo != MATINV_ALGO_GAUSS_JORDAN || !tilep_supports(n))
-            return fail(MATINV_ERR_UNSUPPORTED, "pivoting tile family serves Gauss-Jordan with n <= 128 only (n=%d)", n);
-        e = n > 64 ? launch_gj_tilep4<T>(n, A, X, batch, dInfo, stream) : launch_gj_tilep<T>(n, A, X, batch, dInfo, stream);
+        if (algo != MATINV_ALGO_GAUSS_JORDAN || !(tilep_supports(n) || tilepw_supports(sizeof(T) == 8, n)))
+            return fail(MATINV_ERR_UNSUPPORTED, "pivoting tile family serves Gauss-Jordan with n <= 192 (f64) / 256 (f32) only (n=%d)", n);
+        e = n > 128 ? launch_gj_tilepw<T>(n, A, X, batch, dInfo, stream)
+                    : (n > 64 ? launch_gj_tilep4<T>(n, A, X, batch, dInfo, stream) : launch_gj_tilep<T>(n, A, X, batch, dInfo, stream));
         break;
     case MATINV_KERNEL_ROW:
         if (algo != MATINV_ALGO_GAUSS_JORDAN || !row_family_supports<T>(n))
@@ -647,7 +649,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     case MATINV_KERNEL_ROWLANE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_rowlane(f64, n) : name_gj_rowlane(f64, n);
     case MATINV_KERNEL_TILE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_tile(f64, n) : name_gj_tile(f64, n);
     case MATINV_KERNEL_ROW: return name_gj_row(f64, n);
-    case MATINV_KERNEL_TILEP: return name_gj_tilep(f64, n);
+    case MATINV_KERNEL_TILEP: return n > 128 ? name_gj_tilepw(f64, n) : name_gj_tilep(f64, n);
     case MATINV_KERNEL_GLOBAL: return algo == MATINV_ALGO_CHOLESKY ? name_chol_global(f64) : name_gj_global(f64);
     case MATINV_KERNEL_BLOCKED:
         if (algo == MATINV_ALGO_GAUSS_JORDAN) {

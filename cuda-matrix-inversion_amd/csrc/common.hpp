@@ -185,6 +185,15 @@ hipError_t launch_gj_tilep4_worklist<float>(int n, BatchRef<const float> A, Batc
                                             const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
                                             int *hint_out);
 const char *name_gj_tilep4(bool f64, int n);
+// one wavefront per tile column, 128 < n <= 192 (f64) / 256 (f32), general matrices (tilepw_kernels.hip)
+bool tilepw_supports(bool f64, int n);
+template <class T>
+hipError_t launch_gj_tilepw(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <>
+hipError_t launch_gj_tilepw<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
+template <>
+hipError_t launch_gj_tilepw<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
+const char *name_gj_tilepw(bool f64, int n);
 // second-generation natural-order tile kernel, n <= 64 (tilen_kernels.hip): enqueue only, the caller owns the work list
 template <class T>
 hipError_t enqueue_gj_tilen(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,

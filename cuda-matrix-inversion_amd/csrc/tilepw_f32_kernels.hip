@@ -1,0 +1,12 @@
+// tilepw_f32_kernels.hip -- fp32 instantiations of the pivoting MFMA tile kernel with one wavefront per tile column (tilepw_impl.hpp).
+#include "tilepw_impl.hpp"
+
+namespace matinv {
+
+template <>
+hipError_t launch_gj_tilepw<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream)
+{
+    return launch_tilepw<float>(n, A, X, batch, info, stream);
+}
+
+}  // namespace matinv

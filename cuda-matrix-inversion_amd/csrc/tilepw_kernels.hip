@@ -1,0 +1,21 @@
+// tilepw_kernels.hip -- fp64 instantiations of the pivoting MFMA tile kernel with one wavefront per tile column (tilepw_impl.hpp).
+#include "tilepw_impl.hpp"
+
+namespace matinv {
+
+bool tilepw_supports(bool f64, int n) { return n > 128 && n <= tilepw_limit(f64); }
+
+template <>
+hipError_t launch_gj_tilepw<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream)
+{
+    return launch_tilepw<double>(n, A, X, batch, info, stream);
+}
+
+const char *name_gj_tilepw(bool f64, int n)
+{
+    static thread_local char buf[48];
+    snprintf(buf, sizeof buf, "matinv_gj_tilepw_%s<%d>", f64 ? "f64" : "f32", (n + 15) / 16);
+    return buf;
+}
+
+}  // namespace matinv

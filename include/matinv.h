@@ -59,9 +59,10 @@ typedef enum {
                                   row broadcast through v_readlane; the pivoting path behind the tile family */
     MATINV_KERNEL_GLOBAL = 5,  /* any n <= 1024 (the reference's limit): one 1024-thread workgroup per matrix, working copy
                                   in global memory; the functional path for matrices that do not fit on chip */
-    MATINV_KERNEL_TILEP = 7,   /* n <= 64: the MFMA tile Gauss-Jordan with TRUE partial pivoting inside the kernel (pivot search on the
+    MATINV_KERNEL_TILEP = 7,   /* the MFMA tile Gauss-Jordan with TRUE partial pivoting inside the kernel (pivot search on the
                                   LDS-staged panel, one row per lane; rows never move, the permutation is folded into the store
-                                  addresses): general matrices at MFMA speed */
+                                  addresses): general matrices at MFMA speed. One wavefront per matrix (n <= 64), four
+                                  (n <= 128), one per tile column (n <= 192 in f64, 256 in f32; automatic there) */
     MATINV_KERNEL_BLOCKED = 6  /* any n <= 1024, global-memory working copies, two launches per panel over the whole batch.
                                   MATINV_ALGO_CHOLESKY: blocked right-looking Cholesky, A^-1 = L^-T L^-1 as one symmetric product
                                   (automatic beyond n = 128). MATINV_ALGO_GAUSS_JORDAN: blocked Gauss-Jordan with partial

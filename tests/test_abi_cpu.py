@@ -55,7 +55,11 @@ def test_kernel_selection_is_pure_host_logic():
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 128) == "matinv_gj_tile4_f32<8, true, 4, false>"
     assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 100) == "matinv_gj_tile4_f64<7, false, 4, true>"
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 512) == api.KERNEL_BLOCKED
-    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 150) == api.KERNEL_BLOCKED
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 150) == api.KERNEL_TILEP   # pivoting, one wavefront per tile column
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 192) == api.KERNEL_TILEP
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 193) == api.KERNEL_BLOCKED
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 257) == api.KERNEL_BLOCKED
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160) == "matinv_gj_tilepw_f64<10>"
     with pytest.raises(pkg("_lib").MatinvError):
         api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 4096)
 

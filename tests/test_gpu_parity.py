@@ -283,12 +283,16 @@ def test_cholesky_large_n_blocked(n, batch, dtype, forced):
         assert np.abs(g - g.transpose(0, 2, 1)).max() < (1e-14 if dtype == "f64" else 1e-6) * np.abs(g).max()
 
 
-@pytest.mark.parametrize("n,batch,dtype", [(138, 6, "f64"), (200, 4, "f64"), (333, 3, "f64"), (512, 2, "f32"), (1000, 2, "f32"), (1024, 1, "f64")])
-def test_gauss_jordan_large_n_blocked_general(n, batch, dtype):
-    """General (non-symmetric, needs row exchanges) matrices beyond the LDS limit: blocked Gauss-Jordan with partial
-    pivoting over global-memory working copies (blocked_gj_kernels.hip); ragged panels and tiles, a structurally singular
-    item (zero column: info = that column, NaN result, neighbours untouched), both precisions, and the explicit GLOBAL
-    family as a second opinion."""
+@pytest.mark.parametrize("forced", [False, True])
+@pytest.mark.parametrize("n,batch,dtype", [(129, 7, "f64"), (138, 6, "f64"), (161, 5, "f64"), (192, 5, "f64"), (200, 4, "f64"),
+                                           (333, 3, "f64"), (130, 7, "f32"), (177, 5, "f32"), (230, 4, "f32"), (256, 4, "f32"),
+                                           (512, 2, "f32"), (1000, 2, "f32"), (1024, 1, "f64")])
+def test_gauss_jordan_large_n_blocked_general(n, batch, dtype, forced):
+    """General (non-symmetric, needs row exchanges) matrices beyond the four-wave kernels: up to 12 x 12 (f64) / 16 x 16 (f32)
+    tiles the pivoting MFMA tile kernel with one wavefront per tile column (tilepw_impl.hpp, r02); beyond that -- or forced --
+    blocked Gauss-Jordan with partial pivoting over global-memory working copies (blocked_gj_kernels.hip); ragged panels and
+    tiles, a structurally singular item (zero column: info = that column, NaN result, neighbours untouched), both precisions,
+    and the explicit GLOBAL family as a second opinion."""
     a = general_batch(n, batch, seed=70 + n)
     want, _ = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT)
     cond = max(np.linalg.cond(m) for m in as_mats(a, n))
@@ -298,8 +302,11 @@ def test_gauss_jordan_large_n_blocked_general(n, batch, dtype):
         sing[bad, n // 2, :] = 0.0                        # column n/2 of the last item (memory is [k, col, row])
     np_t = np.float64 if dtype == "f64" else np.float32
     code = api.F64 if dtype == "f64" else api.F32
-    assert api.select_kernel(GJ, code, n) == api.KERNEL_BLOCKED
-    got, info = gpu_inverse(sing.reshape(-1).astype(np_t), n, GJ, want_info=True)
+    wide = n <= (192 if dtype == "f64" else 256)
+    assert api.select_kernel(GJ, code, n) == (api.KERNEL_TILEP if wide else api.KERNEL_BLOCKED)
+    if forced and not wide:
+        pytest.skip("the automatic path is the blocked one already")
+    got, info = gpu_inverse(sing.reshape(-1).astype(np_t), n, GJ, api.KERNEL_BLOCKED if forced else api.KERNEL_AUTO, want_info=True)
     got = got.astype(np.float64)
     ok = batch - 1 if batch > 1 else 1
     if batch > 1:
