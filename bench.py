@@ -46,10 +46,13 @@ WORKLOADS = {
     "gj64g": (64, "gj", "batch x 64x64 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
     "gj32g": (32, "gj", "batch x 32x32 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
     "gj128g": (128, "gj", "batch x 128x128 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
+    "gj192g": (192, "gj", "batch x 192x192 fp64 Gauss-Jordan with partial pivoting (one wavefront per tile column), GENERAL U(0,1) inputs"),
+    "chol192": (192, "chol", "batch x 192x192 fp64 Cholesky inverse (one wavefront per tile column), SPD inputs"),
     "gj256g": (256, "gj", "batch x 256x256 fp64 blocked Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
+    "gj1024g": (1024, "gj", "batch x 1024x1024 fp64 blocked Gauss-Jordan (two-level, MFMA update), GENERAL U(0,1) inputs"),
     "chol256": (256, "chol", "batch x 256x256 fp64 blocked Cholesky inverse, SPD inputs"),
 }
-GENERAL = {"gj64g", "gj32g", "gj128g", "gj256g"}
+GENERAL = {"gj64g", "gj32g", "gj128g", "gj192g", "gj256g", "gj1024g"}
 
 
 def make_spd(n, batch, seed, device):
@@ -223,12 +226,15 @@ def run_mixed(args, api, device, rank, world):
 
 def mfma_flops_per_inversion(algo_name, n):
     """fp64 flops the MFMA tile kernels issue per matrix (None for the families without MFMA): a blocked sweep of 4*NT
-    rank-4 steps over NT^2 tiles (Gauss-Jordan: all tiles = 2 n^3 flop) or over the NT(NT+1)/2 lower tiles (SPD sweep),
-    2048 flop per v_mfma_f64_16x16x4_f64."""
-    if n <= 16 or n > 128 or (algo_name != "gj" and n > 64):
+    rank-4 steps over NT^2 tiles (Gauss-Jordan: all tiles = 2 n^3 flop) or over the NT(NT+1)/2 lower tiles (SPD sweep, one
+    wavefront per matrix: n <= 96; the several-wavefront SPD kernels sweep all tiles), 2048 flop per v_mfma_f64_16x16x4_f64.
+    Blocked two-level Gauss-Jordan (n >= 384): 2 n^3."""
+    if n >= 384 and algo_name == "gj":
+        return 2 * n ** 3
+    if n <= 16 or n > 192:
         return None
     nt = (n + 15) // 16
-    tiles = nt * nt if algo_name == "gj" else nt * (nt + 1) // 2
+    tiles = nt * nt if (algo_name == "gj" or n > 96) else nt * (nt + 1) // 2
     return 4 * nt * tiles * 2048
 
 
@@ -414,12 +420,13 @@ def main():
         # the other single-GPU workloads, a few launches each (same timing method), so that every path -- the weak ones
         # included -- is driver-timed each round
         del a, x
-        for wname in ("gj16", "chol64", "gj32", "gj8", "gj128", "gj64g", "gj32g", "gj128g", "gj256g", "chol256"):
+        for wname in ("gj16", "chol64", "gj32", "gj8", "gj128", "gj64g", "gj32g", "gj128g", "gj192g", "chol192", "gj256g", "chol256",
+                      "gj1024g"):
             if wname == args.workload:
                 continue
             n2, algo2_name, _ = WORKLOADS[wname]
             algo2 = api.ALGO_GAUSS_JORDAN if algo2_name == "gj" else api.ALGO_CHOLESKY
-            b2 = 100_000 if n2 <= 64 else (25_000 if n2 <= 128 else 3_000)
+            b2 = 100_000 if n2 <= 64 else (25_000 if n2 <= 128 else (5_000 if n2 <= 192 else (3_000 if n2 <= 256 else 256)))
             a2 = (make_general if wname in GENERAL else make_spd)(n2, b2, 0x5EED + 17 * n2, device)
             x2 = torch.empty_like(a2)
             i2 = torch.empty(b2, dtype=torch.int32, device=device)
