@@ -88,6 +88,14 @@ def test_device_table_call_sequence_in_c(exe, n, batch):
     assert pitch >= n * n * esz and pitch % 256 == 0
 
 
+@pytest.mark.parametrize("exe", ["queue_test", "queue_test_f32"])
+def test_size_binned_queue_from_c(exe):
+    """matinv_queue_create / submit / flush driven from plain C (README.md:41-44 of the reference; BASELINE configs[4]),
+    checked against the host pipeline (host/gauss_cpu.c)."""
+    lines = run(exe, "12345")
+    assert lines[-1].startswith("queue_test items=120 "), lines
+
+
 @pytest.mark.parametrize("n,k", [(64, 40), (128, 12)])
 def test_sweep_sizes_missing_from_the_reference_tree(tmp_path, n, k):
     """The reference's `make run-inverse-bench` / `run-gauss-bench` sweeps go up to 128x128, but its 64 / 128 fixtures are
