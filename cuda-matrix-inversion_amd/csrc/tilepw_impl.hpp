@@ -3,16 +3,16 @@
 // WAVEFRONT PER TILE COLUMN, NT = 9 .. 16 wavefronts per matrix, one workgroup per CU -- the matrix fills most of the CU's
 // register file (12 x 12 fp64 tiles = 1 152 of 2 048 VGPRs per lane).
 //
-// Same structure as the four-wave kernel: the owner of the pivot columns stages them into a double-buffered LDS panel, one
-// workgroup barrier per block step, every wave runs the search and the in-place Gauss-Jordan of the n x 4 panel redundantly
-// (R = ceil(n / 64) rows per lane), gathers its part of the four pivot rows from its own registers through a private LDS
-// strip, transposes Aop out of the search registers. Differences:
+// Same structure as the four-wave kernel: the owner of the pivot columns of a block is the one wave that searches it (R =
+// ceil(n / 64) rows per lane) and publishes the finished panel, the pivots and the singular flag in a double-buffered LDS
+// block, one workgroup barrier per block step; every wave gathers its part of the four pivot rows from its own registers
+// through a private LDS strip and reads its A operand from the published panel. Differences:
 //   * the kernel works on W = A itself, not on A^T (loads and stores are 32-byte segments instead of 128-byte ones; at these
 //     sizes the kernel is far from memory-bound): the row search then IS the oracle's partial pivoting, so a singular
 //     matrix is finished here with the oracle's info code (first column without a usable pivot + 1) and a NaN-filled output --
 //     there is no kernel behind this one that serves every such n;
 //   * each wave has one tile column, so all of its MFMAs of a block step run before the next panel is staged (nothing to
-//     interleave with the search; the other waves of the SIMD fill in).
+//     interleave with the search; the waves of the other workgroup phases fill in).
 // Replaces, for general matrices of these sizes, the 2 n / 32 + 2 launches of the blocked path (blocked_gj_kernels.hip).
 #pragma once
 #include "tilep_impl.hpp"
@@ -70,7 +70,7 @@ struct GatherAllRows {
 
 template <class T, int NT>
 __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n, unsigned batch, T *panel2,
-                                               T *bball, unsigned char *tab)
+                                               T *bball, unsigned char *tab, T *aopl, int *pvl)
 {
     static_assert(NT >= 9 && NT <= 16, "one wavefront per tile column: 128 < n <= 256");
     typedef TileGeo<T> G;
@@ -114,28 +114,33 @@ __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T
             constexpr int tKn = decltype(tKc)::value;  // = the owner wave
             constexpr bool first = decltype(firstc)::value != 0;
             const bool panel_lane = G::blk(c) == rKn;
-            T *const pbuf = panel2 + ((4 * tKn + rKn) & 1) * (N * 4);
+            const bool is_owner = w == tKn;  // wave-uniform: the ONE wave that searches this block
+            T *const pbuf = panel2;          // touched by the owner only
+            const int par = (4 * tKn + rKn) & 1;
+            T *const abuf = aopl + par * (N * 4);
+            int *const pbufi = pvl + par * 8;
             if (!first) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti) acc[ti][0] = G::mfma(aop[ti], bop, acc[ti][0]);
             }
-            if (w == tKn && panel_lane) {
+            if (is_owner && panel_lane) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pbuf[(16 * ti + G::trow(r, q)) * 4 + G::piv(c)] = acc[ti][0][r];
             }
-            __syncthreads();
+            wave_lds_sync();  // the panel never leaves the owner wave
             T a[R][4];
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
                 vec4 v = {};
-                if (lr + 64 * rr < N) v = *reinterpret_cast<const vec4 *>(&pbuf[(lr + 64 * rr) * 4]);
+                if (is_owner && lr + 64 * rr < N) v = *reinterpret_cast<const vec4 *>(&pbuf[(lr + 64 * rr) * 4]);
                 a[rr][0] = v[0], a[rr][1] = v[1], a[rr][2] = v[2], a[rr][3] = v[3];
             }
             int pv = 0;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (!is_owner) continue;  // the other waves wait at the barrier below
                 // largest |.| over the unused rows; lowest row on ties (rows of one lane set first, then the next set)
                 unsigned key[R], kmax = 0;
 #pragma unroll
@@ -180,21 +185,33 @@ __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T
                     a[rr][t] = me ? rp : f;
                 }
             }
-            // A operand: lane (q, c) needs Aop[16 ti + c][q]; rows 64 rr .. 64 rr + 63 sit in a[rr] (lane group ti - 4 rr)
+            // The owner publishes the finished panel (row i = Aop[i, 0:4]), the four pivot slots, the singular flag and the
+            // permutation tables (double-buffered); ONE workgroup barrier; every wave picks up its A operand and the pivots.
+            if (is_owner) {
 #pragma unroll
-            for (int rr = 0; rr < R; ++rr) {
-                lane_rows_swap<true>(a[rr][0], a[rr][2]);
-                lane_rows_swap<true>(a[rr][1], a[rr][3]);
-                lane_rows_swap<false>(a[rr][0], a[rr][1]);
-                lane_rows_swap<false>(a[rr][2], a[rr][3]);
+                for (int rr = 0; rr < R; ++rr) {
+                    vec4 v;
+                    v[0] = a[rr][0], v[1] = a[rr][1], v[2] = a[rr][2], v[3] = a[rr][3];
+                    if (lr + 64 * rr < N) *reinterpret_cast<vec4 *>(&abuf[(lr + 64 * rr) * 4]) = v;
+                }
+                if (lr < 4) {
+                    pbufi[lr] = pv;
+                    const int j = 16 * tKn + G::pcol(rKn, lr);
+                    coladdr[j] = (unsigned char)pv;
+                    rowaddr[pv] = (unsigned char)j;
+                }
+                if (lr == 4) pbufi[4] = bad;
             }
+            __syncthreads();
 #pragma unroll
-            for (int ti = 0; ti < NT; ++ti) aop[ti] = a[ti / 4][ti % 4];
-            // permutation tables (every wave writes the same values)
-            if (lr < 4) {
-                const int j = 16 * tKn + G::pcol(rKn, lr);
-                coladdr[j] = (unsigned char)pv;
-                rowaddr[pv] = (unsigned char)j;
+            for (int ti = 0; ti < NT; ++ti) aop[ti] = abuf[(16 * ti + c) * 4 + q];
+            pv = pbufi[lr & 3];  // lane t (and t + 4, ...) holds the slot of pivot t
+            if (bad == 0) bad = pbufi[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int s = __builtin_amdgcn_readlane(pv, t);
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) used[rr] = used[rr] || (lr + 64 * rr == s);
             }
             // B operand: this wave's part of the four pivot rows through its LDS strip (and zero it in C)
 #pragma nounroll
@@ -292,20 +309,24 @@ template <int NT>
 __global__ __launch_bounds__(64 * NT, 1) void matinv_gj_tilepw_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n,
                                                                   unsigned batch)
 {
-    __shared__ __attribute__((aligned(16))) double panel2[2 * 16 * NT * 4];
+    __shared__ __attribute__((aligned(16))) double panel2[16 * NT * 4];       // the owner's panel, one row per lane back
+    __shared__ __attribute__((aligned(16))) double aopl[2 * 16 * NT * 4];     // the finished panel = A operand, double buffered
     __shared__ __attribute__((aligned(16))) double bball[NT * 4 * 16];
+    __shared__ int pvl[16];
     __shared__ unsigned char tab[512];
-    gj_tilepw_body<double, NT>(Ain, Xout, info, n, batch, panel2, bball, tab);
+    gj_tilepw_body<double, NT>(Ain, Xout, info, n, batch, panel2, bball, tab, aopl, pvl);
 }
 
 template <int NT>
 __global__ __launch_bounds__(64 * NT, 1) void matinv_gj_tilepw_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n,
                                                                   unsigned batch)
 {
-    __shared__ __attribute__((aligned(16))) float panel2[2 * 16 * NT * 4];
+    __shared__ __attribute__((aligned(16))) float panel2[16 * NT * 4];       // the owner's panel, one row per lane back
+    __shared__ __attribute__((aligned(16))) float aopl[2 * 16 * NT * 4];     // the finished panel = A operand, double buffered
     __shared__ __attribute__((aligned(16))) float bball[NT * 4 * 16];
+    __shared__ int pvl[16];
     __shared__ unsigned char tab[512];
-    gj_tilepw_body<float, NT>(Ain, Xout, info, n, batch, panel2, bball, tab);
+    gj_tilepw_body<float, NT>(Ain, Xout, info, n, batch, panel2, bball, tab, aopl, pvl);
 }
 
 constexpr int tilepw_limit(bool f64) { return f64 ? 192 : 256; }

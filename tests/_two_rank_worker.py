@@ -24,7 +24,7 @@ def main():
     ok = True
     for n, batch, algo, gen in ((8, 1003, 0, spd_batch), (16, 1001, 0, spd_batch), (64, 300, 0, spd_batch),
                                 (64, 300, 1, spd_batch), (64, 257, 0, general_batch), (128, 41, 0, spd_batch),
-                                (200, 9, 0, general_batch)):
+                                (160, 33, 0, general_batch), (176, 21, 1, spd_batch), (200, 9, 0, general_batch)):
         a = gen(n, batch, seed=100 + n)
         lo, hi = shard.partition(batch, world, shard.packing_multiple(n))[rank]
         mine = torch.from_numpy(a[lo * n * n: hi * n * n]).cuda()
