@@ -3,15 +3,18 @@
 //
 // As in tile4_impl.hpp a 256-thread workgroup owns a matrix and wavefront w holds the tile columns w and w + 4 (all NT tile
 // rows of them, <= 16 tiles). What the pivot search adds to that split:
-//   * the wave that owns the pivot columns of a block is the ONE wave that searches it: it stages them into LDS (its own
-//     strip: no barrier), runs the search and the in-place Gauss-Jordan of the n x 4 panel with two rows per lane (rows l
-//     and l + 64) between its MFMAs, and publishes the finished panel (= the A operand), the four pivot slots and the
-//     singular flag in a double-buffered LDS block; ONE workgroup barrier per block step; the other three waves only have
-//     their MFMAs until then;
+//   * the wave that owns the pivot columns stages them into a double-buffered LDS panel, ONE workgroup barrier per block
+//     step; then EVERY wave runs the search and the in-place Gauss-Jordan of the n x 4 panel redundantly, two rows per
+//     lane (rows l and l + 64): no second exchange, and pivots, A operand and permutation come out identical in all four;
 //   * the B operand (the four pivot rows) is local: each wave gathers the part of the pivot rows that lies in ITS tile
 //     columns from its own registers through a private 1 KB LDS strip (run-time register index: the asm blocks of
 //     gather_zero_tile_row, two tile columns wide here) and zeroes it in C;
-//   * every wave reads its A operand Aop[16 ti + c][q] from the published panel (8 ds_read_b64).
+//   * the A operand comes out of the search registers by the same lane-group transposes (permlane swaps), once for the
+//     rows below 64 and once for the rows above.
+// (Measured and not kept here: ONE searching wave per block -- the owner -- publishing the finished panel through LDS while the
+// other three only run their MFMAs until the barrier. It removes 3/4 of the search instructions and loses 10 %: 3.8e6 inv/s
+// at 128 x 128 f64 against 4.2e6, 6.1e6 against 6.8e6 at 96 x 96 -- with four waves the search of ONE wave is the critical
+// path either way, and the redundant version needs no second LDS trip. tilepw_impl.hpp, 9-16 waves per matrix, does gain.)
 // Look-ahead as in the one-wave kernel: the local tile column that (for the next owner) holds the next pivot columns is
 // updated first, the next panel is staged, and the other column's MFMAs run pinned between the stages of the next search.
 //
@@ -74,7 +77,7 @@ __device__ __forceinline__ void gather_zero_tile_row2(typename TileGeo<T>::vec4 
 template <class T, int NT, bool FULL>
 __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
                                                T *panel2, T *bball, unsigned char *tab, int *bad_count, int *bad_list,
-                                               const int *in_count, const int *in_list, int *hint_out, T *aopl, int *pvl)
+                                               const int *in_count, const int *in_list, int *hint_out)
 {
     static_assert(NT >= 5 && NT <= 8, "four wavefronts serve 64 < n <= 128");
     typedef TileGeo<T> G;
@@ -129,11 +132,7 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
             constexpr int owner = tKn % W, jo = tKn / W;  // wave and local column holding the pivot columns of this block
             constexpr int NB = first ? 0 : NT * (NC - 1);
             const bool panel_lane = G::blk(c) == rKn;
-            const bool is_owner = w == owner;  // wave-uniform: the ONE wave that searches this block
-            T *const pbuf = panel2;            // touched by the owner only
-            const int par = (4 * tKn + rKn) & 1;
-            T *const abuf = aopl + par * (N * 4);
-            int *const pbufi = pvl + par * 8;
+            T *const pbuf = panel2 + ((4 * tKn + rKn) & 1) * (N * 4);
             // tile columns beyond NT (second local column of the last waves when NT < 8) hold zeros and are left alone
             const bool have_jo = w + W * jo < NT, have_other = w + W * (1 - jo) < NT;  // wave-uniform
             if (!first && have_jo) {
@@ -153,19 +152,17 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
             };
             __builtin_amdgcn_sched_barrier(0);
             issue_b(2);
-            if (is_owner && panel_lane) {
+            if (w == owner && panel_lane) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pbuf[(16 * ti + G::trow(r, q)) * 4 + G::piv(c)] = acc[ti][jo][r];
             }
-            wave_lds_sync();  // the panel never leaves the owner wave
+            __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
-            vec4 wlo = {}, whi = {};
-            if (is_owner) {
-                wlo = *reinterpret_cast<const vec4 *>(&pbuf[lr * 4]);
-                if (lr + 64 < N) whi = *reinterpret_cast<const vec4 *>(&pbuf[(lr + 64) * 4]);
-            }
+            const vec4 wlo = *reinterpret_cast<const vec4 *>(&pbuf[lr * 4]);
+            vec4 whi = {};
+            if (lr + 64 < N) whi = *reinterpret_cast<const vec4 *>(&pbuf[(lr + 64) * 4]);
             T a0[4] = {wlo[0], wlo[1], wlo[2], wlo[3]}, a1[4] = {whi[0], whi[1], whi[2], whi[3]};
             T u[4] = {};
             T rp = (T)0;
@@ -175,7 +172,6 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
             for (int st = 0; st < NS; ++st) {
                 const int t = st / 3;
                 issue_b(((NB - 2) * (st + 1)) / NS - ((NB - 2) * st) / NS);
-                if (!is_owner) continue;  // the other three waves only have their MFMAs here, then wait at the barrier
                 if (st % 3 == 0) {
                     const unsigned k0 = used_lo ? 0u : magkey(a0[t]), k1 = used_hi ? 0u : magkey(a1[t]);
                     const unsigned mx = wave_max_u32(k0 > k1 ? k0 : k1);
@@ -206,34 +202,22 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
                 __builtin_amdgcn_sched_barrier(0);
             }
             issue_b(NB);
-            // The owner publishes the finished panel (row i = Aop[i, 0:4]), the four pivot slots, the singular flag and the
-            // permutation tables; ONE workgroup barrier; every wave picks up its A operand Aop[16 ti + c][q] and the pivots.
-            // (r02, first version: every wave ran the search itself -- 47 k VALU instructions per 128 x 128 matrix, waves
-            // waiting 2/3 of their time. Double-buffered: the next owner writes the other half while slow waves still read.)
-            if (is_owner) {
-                vec4 v0, v1;
-                v0[0] = a0[0], v0[1] = a0[1], v0[2] = a0[2], v0[3] = a0[3];
-                v1[0] = a1[0], v1[1] = a1[1], v1[2] = a1[2], v1[3] = a1[3];
-                *reinterpret_cast<vec4 *>(&abuf[lr * 4]) = v0;
-                if (lr + 64 < N) *reinterpret_cast<vec4 *>(&abuf[(lr + 64) * 4]) = v1;
-                if (lr < 4) {
-                    pbufi[lr] = pv;
-                    const int j = 16 * tKn + G::pcol(rKn, lr);
-                    coladdr[j] = (unsigned char)pv;
-                    rowaddr[pv] = (unsigned char)j;
-                }
-                if (lr == 4) pbufi[4] = bad;
-            }
-            __syncthreads();
+            // A operand: lane (q, c) needs Aop[16 ti + c][q]; rows below 64 sit in a0 (lane group ti), rows above in a1
+            lane_rows_swap<true>(a0[0], a0[2]);
+            lane_rows_swap<true>(a0[1], a0[3]);
+            lane_rows_swap<false>(a0[0], a0[1]);
+            lane_rows_swap<false>(a0[2], a0[3]);
+            lane_rows_swap<true>(a1[0], a1[2]);
+            lane_rows_swap<true>(a1[1], a1[3]);
+            lane_rows_swap<false>(a1[0], a1[1]);
+            lane_rows_swap<false>(a1[2], a1[3]);
 #pragma unroll
-            for (int ti = 0; ti < NT; ++ti) aop[ti] = abuf[(16 * ti + c) * 4 + q];
-            pv = pbufi[lr & 3];        // lane t (and t + 4, ...) holds the slot of pivot t
-            bad |= pbufi[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int s = __builtin_amdgcn_readlane(pv, t);
-                used_lo = used_lo || (lr == s);
-                used_hi = used_hi || (lr + 64 == s);
+            for (int ti = 0; ti < NT; ++ti) aop[ti] = ti < 4 ? a0[ti] : a1[ti - 4];
+            // permutation tables (every wave writes the same values)
+            if (lr < 4) {
+                const int j = 16 * tKn + G::pcol(rKn, lr);
+                coladdr[j] = (unsigned char)pv;
+                rowaddr[pv] = (unsigned char)j;
             }
             // B operand: this wave's part of the four pivot rows through its LDS strip (and zero it in C)
 #pragma nounroll
@@ -346,12 +330,10 @@ __global__ __launch_bounds__(256, 2) void matinv_gj_tilep4_f64(BatchRef<const do
                                                               unsigned batch, int *bad_count, int *bad_list, const int *in_count,
                                                               const int *in_list, int *hint_out)
 {
-    __shared__ __attribute__((aligned(16))) double panel2[16 * NT * 4];       // the owner's panel, one row per lane back
-    __shared__ __attribute__((aligned(16))) double aopl[2 * 16 * NT * 4];     // the finished panel = A operand, double buffered
+    __shared__ __attribute__((aligned(16))) double panel2[2 * 16 * NT * 4];
     __shared__ __attribute__((aligned(16))) double bball[4 * 4 * 32];
-    __shared__ int pvl[16];
     __shared__ unsigned char tab[256];
-    gj_tilep4_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out, aopl, pvl);
+    gj_tilep4_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out);
 }
 
 template <int NT, bool FULL>
@@ -359,12 +341,10 @@ __global__ __launch_bounds__(256, 3) void matinv_gj_tilep4_f32(BatchRef<const fl
                                                               unsigned batch, int *bad_count, int *bad_list, const int *in_count,
                                                               const int *in_list, int *hint_out)
 {
-    __shared__ __attribute__((aligned(16))) float panel2[16 * NT * 4];       // the owner's panel, one row per lane back
-    __shared__ __attribute__((aligned(16))) float aopl[2 * 16 * NT * 4];     // the finished panel = A operand, double buffered
+    __shared__ __attribute__((aligned(16))) float panel2[2 * 16 * NT * 4];
     __shared__ __attribute__((aligned(16))) float bball[4 * 4 * 32];
-    __shared__ int pvl[16];
     __shared__ unsigned char tab[256];
-    gj_tilep4_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out, aopl, pvl);
+    gj_tilep4_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out);
 }
 
 template <class T>
