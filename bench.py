@@ -436,7 +436,7 @@ def main():
             ms2 = float(np.mean(time_launches(lambda: api.inverse_batched(a2, n2, algo2, out=x2, batch=b2), 5)))
             r1, r2 = rooflines(algo2_name, n2, b2, ms2)
             kname2 = api.kernel_name(algo2, api.F64, n2)
-            if wname in GENERAL and 16 < n2 <= 128:
+            if wname in GENERAL and 16 < n2 <= 192:
                 kname2 = api.kernel_name(algo2, api.F64, n2, api.KERNEL_TILEP)  # where the adaptive dispatch sends a general batch
             others[wname] = {"kernel": kname2, "batch": b2, "kernel_ms": ms2, "input": "general U(0,1)" if wname in GENERAL else "SPD",
                              "inversions_per_s": b2 / (ms2 * 1e-3), "bound": r1["bound"], "frac": r1["frac"],
@@ -447,7 +447,7 @@ def main():
     if rank == 0:
         value = total_batch * args.steps / elapsed
         kname = api.kernel_name(algo, api.F64, n, kernel)
-        if general and 16 < n <= 128 and kernel == api.KERNEL_AUTO:
+        if general and 16 < n <= 192 and kernel == api.KERNEL_AUTO:
             kname = api.kernel_name(algo, api.F64, n, api.KERNEL_TILEP)  # where the adaptive dispatch sends a general batch
         roof, roof_other = rooflines(algo_name, n, batch, kern_ms)
         traffic, traffic_src = load_traffic(kname, n, batch)

@@ -137,7 +137,7 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
             break;
         }
         if (!tile_family_supports<T>(n))
-            return fail(MATINV_ERR_UNSUPPORTED, "tile family serves Gauss-Jordan with n <= 128 only (n=%d)", n);
+            return fail(MATINV_ERR_UNSUPPORTED, "tile family serves Gauss-Jordan with n <= 192 (f64) / 256 (f32) only (n=%d)", n);
         e = launch_gj_tile<T>(n, A, X, batch, dInfo, stream);
         break;
     case MATINV_KERNEL_GLOBAL:

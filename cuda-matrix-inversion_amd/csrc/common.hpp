@@ -193,6 +193,15 @@ template <>
 hipError_t launch_gj_tilepw<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
 template <>
 hipError_t launch_gj_tilepw<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+hipError_t launch_gj_tilepw_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count, const int *in_list,
+                                     int *info, hipStream_t stream, int *hint_out);
+template <>
+hipError_t launch_gj_tilepw_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
+                                             const int *in_list, int *info, hipStream_t stream, int *hint_out);
+template <>
+hipError_t launch_gj_tilepw_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
+                                            const int *in_list, int *info, hipStream_t stream, int *hint_out);
 const char *name_gj_tilepw(bool f64, int n);
 // second-generation natural-order tile kernel, n <= 64 (tilen_kernels.hip): enqueue only, the caller owns the work list
 template <class T>

@@ -46,10 +46,10 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                                               int *work_count, int *work_list, T *panel, GpArgs<T> gp = GpArgs<T>())
 {
     static_assert(!GP || SPD, "the fused pipeline runs the SPD sweep");
-    static_assert(NT <= 8 || SPD, "more than 8 x 8 tiles: SPD sweep only (a rejected general matrix would need a pivoting kernel of that size)");
-    // NT > 8: no kernel behind this one serves every such n, so a matrix that is not positive definite is finished here:
-    // info = the column of the first non-positive pivot + 1 (the Cholesky contract), output NaN-filled
-    constexpr bool SELF = NT > 8;
+    // NT > 8, SPD sweep: no Cholesky kernel behind this one serves every such n, so a matrix that is not positive definite is
+    // finished here: info = the column of the first non-positive pivot + 1 (the Cholesky contract), output NaN-filled.
+    // (Gauss-Jordan, NT > 8: rejected = needs row exchanges -> work list -> the pivoting kernel of that size, tilepw_impl.hpp)
+    constexpr bool SELF = NT > 8 && SPD;
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
     constexpr int N = 16 * NT;
@@ -350,11 +350,12 @@ constexpr bool gp_tile4_wide_supports(bool f64, int n) { return n > 128 && n <= 
 template <class T, bool SPD>
 static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
-    if (!(tile4_supports(n) || (SPD && n > 128 && n <= t4_wide_limit(sizeof(T) == 8)))) return hipErrorInvalidValue;
+    if (!(tile4_supports(n) || (n > 128 && n <= t4_wide_limit(sizeof(T) == 8)))) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    // Gauss-Jordan: general batches go straight to the four-wave PIVOTING kernel once a natural-order launch of this size
+    // Gauss-Jordan: general batches go straight to the PIVOTING kernel of this size once a natural-order launch of this size
     // has seen most of its matrices rejected (tile_kernels.inc "natural order or pivot search?")
-    if (!SPD && tile_policy_use_pivot(sizeof(T) == 8, (n + 15) / 16)) return launch_gj_tilep4<T>(n, A, X, batch, info, stream);
+    if (!SPD && tile_policy_use_pivot(sizeof(T) == 8, (n + 15) / 16))
+        return n > 128 ? launch_gj_tilepw<T>(n, A, X, batch, info, stream) : launch_gj_tilep4<T>(n, A, X, batch, info, stream);
     // [0], [1] = counts; [2 .. batch+2) = rejected matrices; [batch+2 ..) = (Gauss-Jordan) the singular ones among them
     int *ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (2 * batch + 2) * sizeof(int), stream);
@@ -368,9 +369,9 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     const unsigned resident = nt > 8 ? 256u : 256u * 3u;  // NT wavefronts per matrix: one workgroup per CU
     const unsigned grid = (unsigned)(batch < resident * tile_grid_rounds() ? batch : resident * tile_grid_rounds());
     const unsigned b = (unsigned)batch;
-// more than 8 x 8 tiles: run-time n only, SPD only, f64 up to 12 x 12
+// more than 8 x 8 tiles: run-time n only, f64 up to 12 x 12
 #define T4_WIDE(NT_)                                                                                                  \
-    if constexpr (SPD && (sizeof(T) == 4 || NT_ <= 12)) {                                                             \
+    if constexpr (sizeof(T) == 4 || NT_ <= 12) {                                                             \
         if constexpr (sizeof(T) == 8)                                                                                 \
             hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 2); \
         else                                                                                                          \
@@ -405,11 +406,15 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 #undef T4_LAUNCH
 #undef T4_WIDE
     e = hipGetLastError();
-    if (e == hipSuccess && nt <= 8) {  // beyond 8 x 8 tiles the kernel finishes its rejects itself
-        if (SPD) e = launch_chol_lds_worklist<T>(n, A, X, ws, ws + 2, info, stream);
-        else  // rejected = needs row exchanges: the four-wave PIVOTING kernel, in the same stream
+    if (e == hipSuccess) {
+        if (SPD) {  // beyond 8 x 8 tiles the SPD kernel finishes its rejects itself
+            if (nt <= 8) e = launch_chol_lds_worklist<T>(n, A, X, ws, ws + 2, info, stream);
+        } else if (nt <= 8) {  // rejected = needs row exchanges: the PIVOTING kernel of this size, in the same stream
             e = launch_gj_tilep4_worklist<T>(n, A, X, batch, ws, ws + 2, ws + 1, ws + 2 + batch, info, stream,
                                              tile_policy_record(sizeof(T) == 8, nt, batch));
+        } else {
+            e = launch_gj_tilepw_worklist<T>(n, A, X, batch, ws, ws + 2, info, stream, tile_policy_record(sizeof(T) == 8, nt, batch));
+        }
     }
     hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;

@@ -9,4 +9,11 @@ hipError_t launch_gj_tilepw<float>(int n, BatchRef<const float> A, BatchRef<floa
     return launch_tilepw<float>(n, A, X, batch, info, stream);
 }
 
+template <>
+hipError_t launch_gj_tilepw_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
+                                            const int *in_list, int *info, hipStream_t stream, int *hint_out)
+{
+    return launch_tilepw<float>(n, A, X, batch, info, stream, in_count, in_list, hint_out);
+}
+
 }  // namespace matinv

@@ -70,7 +70,8 @@ struct GatherAllRows {
 
 template <class T, int NT>
 __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n, unsigned batch, T *panel2,
-                                               T *bball, unsigned char *tab, T *aopl, int *pvl)
+                                               T *bball, unsigned char *tab, T *aopl, int *pvl, const int *in_count, const int *in_list,
+                                               int *hint_out)
 {
     static_assert(NT >= 9 && NT <= 16, "one wavefront per tile column: 128 < n <= 256");
     typedef TileGeo<T> G;
@@ -85,7 +86,12 @@ __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T
     typedef __attribute__((address_space(3))) T *lds_ptr;
     const unsigned bb_lane = (unsigned)(size_t)(lds_ptr)(bbuf + (l & 15));
 
-    for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
+    // work-list form (the matrices the natural-order kernel of this size rejected): in_list[0 .. *in_count); its length goes
+    // back to the launcher's natural / pivot guess through pinned host memory (see tilep_impl.hpp)
+    const unsigned todo = in_count ? (unsigned)*in_count : batch;
+    if (hint_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint_out, (int)todo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (unsigned item = blockIdx.x; item < todo; item += gridDim.x) {
+        const unsigned mat = in_list ? (unsigned)in_list[item] : item;
         const T *A = Ain.at_uniform(mat);
         T *X = Xout.at_uniform(mat);
         int nn = n;
@@ -307,44 +313,46 @@ __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T
 
 template <int NT>
 __global__ __launch_bounds__(64 * NT, 1) void matinv_gj_tilepw_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n,
-                                                                  unsigned batch)
+                                                                  unsigned batch, const int *in_count, const int *in_list, int *hint_out)
 {
     __shared__ __attribute__((aligned(16))) double panel2[16 * NT * 4];       // the owner's panel, one row per lane back
     __shared__ __attribute__((aligned(16))) double aopl[2 * 16 * NT * 4];     // the finished panel = A operand, double buffered
     __shared__ __attribute__((aligned(16))) double bball[NT * 4 * 16];
     __shared__ int pvl[16];
     __shared__ unsigned char tab[512];
-    gj_tilepw_body<double, NT>(Ain, Xout, info, n, batch, panel2, bball, tab, aopl, pvl);
+    gj_tilepw_body<double, NT>(Ain, Xout, info, n, batch, panel2, bball, tab, aopl, pvl, in_count, in_list, hint_out);
 }
 
 template <int NT>
 __global__ __launch_bounds__(64 * NT, 1) void matinv_gj_tilepw_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n,
-                                                                  unsigned batch)
+                                                                  unsigned batch, const int *in_count, const int *in_list, int *hint_out)
 {
     __shared__ __attribute__((aligned(16))) float panel2[16 * NT * 4];       // the owner's panel, one row per lane back
     __shared__ __attribute__((aligned(16))) float aopl[2 * 16 * NT * 4];     // the finished panel = A operand, double buffered
     __shared__ __attribute__((aligned(16))) float bball[NT * 4 * 16];
     __shared__ int pvl[16];
     __shared__ unsigned char tab[512];
-    gj_tilepw_body<float, NT>(Ain, Xout, info, n, batch, panel2, bball, tab, aopl, pvl);
+    gj_tilepw_body<float, NT>(Ain, Xout, info, n, batch, panel2, bball, tab, aopl, pvl, in_count, in_list, hint_out);
 }
 
 constexpr int tilepw_limit(bool f64) { return f64 ? 192 : 256; }
 
+// in_count / in_list != nullptr: work-list form (one round of resident workgroups; usually empty)
 template <class T>
-static hipError_t launch_tilepw(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+static hipError_t launch_tilepw(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
+                                const int *in_count = nullptr, const int *in_list = nullptr, int *hint_out = nullptr)
 {
     if (n <= 128 || n > tilepw_limit(sizeof(T) == 8)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     const int nt = (n + 15) / 16;
-    const unsigned cap = 256u * tile_grid_rounds();
+    const unsigned cap = in_list ? 256u : 256u * tile_grid_rounds();
     const unsigned grid = (unsigned)(batch < cap ? batch : cap);
     const unsigned b = (unsigned)batch;
 #define TPW_LAUNCH(NT_)                                                                                                \
     if constexpr (sizeof(T) == 8) {                                                                                    \
-        if constexpr (NT_ <= 12) hipLaunchKernelGGL((matinv_gj_tilepw_f64<NT_>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b); \
+        if constexpr (NT_ <= 12) hipLaunchKernelGGL((matinv_gj_tilepw_f64<NT_>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, in_count, in_list, hint_out); \
     } else {                                                                                                           \
-        hipLaunchKernelGGL((matinv_gj_tilepw_f32<NT_>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b);        \
+        hipLaunchKernelGGL((matinv_gj_tilepw_f32<NT_>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, in_count, in_list, hint_out);        \
     }
     switch (nt) {
     case 9: TPW_LAUNCH(9) break;

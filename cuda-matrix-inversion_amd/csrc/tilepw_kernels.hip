@@ -11,6 +11,13 @@ hipError_t launch_gj_tilepw<double>(int n, BatchRef<const double> A, BatchRef<do
     return launch_tilepw<double>(n, A, X, batch, info, stream);
 }
 
+template <>
+hipError_t launch_gj_tilepw_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
+                                            const int *in_list, int *info, hipStream_t stream, int *hint_out)
+{
+    return launch_tilepw<double>(n, A, X, batch, info, stream, in_count, in_list, hint_out);
+}
+
 const char *name_gj_tilepw(bool f64, int n)
 {
     static thread_local char buf[48];

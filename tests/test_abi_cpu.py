@@ -39,7 +39,7 @@ def test_library_exports_17_reference_names_both_precisions():
 
 def test_kernel_selection_is_pure_host_logic():
     api = pkg("api")
-    for n in (1, 8, 16, 32, 64, 128):
+    for n in (1, 8, 16, 32, 64, 128, 192):
         k = api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, n)
         assert k in (api.KERNEL_ROWLANE, api.KERNEL_TILE)
         assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, n).startswith("matinv_")
@@ -55,11 +55,12 @@ def test_kernel_selection_is_pure_host_logic():
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 128) == "matinv_gj_tile4_f32<8, true, 4, false>"
     assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 100) == "matinv_gj_tile4_f64<7, false, 4, true>"
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 512) == api.KERNEL_BLOCKED
-    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 150) == api.KERNEL_TILEP   # pivoting, one wavefront per tile column
-    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 192) == api.KERNEL_TILEP
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 150) == api.KERNEL_TILE   # one wavefront per tile column
+    assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 192) == api.KERNEL_TILE
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 193) == api.KERNEL_BLOCKED
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 257) == api.KERNEL_BLOCKED
-    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160) == "matinv_gj_tilepw_f64<10>"
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160) == "matinv_gj_tile4_f64<10, false, 10, false>"
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160, api.KERNEL_TILEP) == "matinv_gj_tilepw_f64<10>"
     with pytest.raises(pkg("_lib").MatinvError):
         api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 4096)
 

@@ -153,7 +153,7 @@ def test_square_fixtures_pivoting(f, n, gold):
         assert rel_err(gpu_inverse(a, n, GJ, api.KERNEL_TILEP), gold[f + "/gj"], n) < 1e-10
 
 
-@pytest.mark.parametrize("n", [20, 32, 50, 64, 72, 100, 128])
+@pytest.mark.parametrize("n", [20, 32, 50, 64, 72, 100, 128, 150, 192])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_tile_family_pivots_inside_the_kernel(n, dtype):
     """General batches through the tile family: the first launch tries the natural order, every matrix it rejects is
@@ -303,7 +303,7 @@ def test_gauss_jordan_large_n_blocked_general(n, batch, dtype, forced):
     np_t = np.float64 if dtype == "f64" else np.float32
     code = api.F64 if dtype == "f64" else api.F32
     wide = n <= (192 if dtype == "f64" else 256)
-    assert api.select_kernel(GJ, code, n) == (api.KERNEL_TILEP if wide else api.KERNEL_BLOCKED)
+    assert api.select_kernel(GJ, code, n) == (api.KERNEL_TILE if wide else api.KERNEL_BLOCKED)
     if forced and not wide:
         pytest.skip("the automatic path is the blocked one already")
     got, info = gpu_inverse(sing.reshape(-1).astype(np_t), n, GJ, api.KERNEL_BLOCKED if forced else api.KERNEL_AUTO, want_info=True)

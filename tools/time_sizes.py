@@ -24,4 +24,4 @@ for n in map(int, sys.argv[3:]):
     ms = sorted(s.elapsed_time(e) for s, e in ev)[2]
     resid = (torch.bmm(a.view(batch, n, n)[:4], x.view(batch, n, n)[:4]) - torch.eye(n, device="cuda", dtype=dtype)).abs().max().item()
     print(f"n={n:4d} batch={batch:6d} {ms:8.3f} ms  {batch / ms * 1e3:12.4e} inv/s  {batch * 2 * n * n * a.element_size() / ms / 1e6:8.1f} GB/s  resid {resid:.1e}  "
-          f"{api.kernel_name(algo, api.F64 if dtype == torch.float64 else api.F32, n, api.KERNEL_TILEP if (general and kernel == api.KERNEL_AUTO and 16 < n <= 128 and algo == api.ALGO_GAUSS_JORDAN) else kernel)}", flush=True)
+          f"{api.kernel_name(algo, api.F64 if dtype == torch.float64 else api.F32, n, api.KERNEL_TILEP if (general and kernel == api.KERNEL_AUTO and 16 < n <= (192 if dtype == torch.float64 else 256) and algo == api.ALGO_GAUSS_JORDAN) else kernel)}", flush=True)
