@@ -15,6 +15,10 @@
 // count is 2 n / PB per batch -- this replaces the reference's 4N+1 launches per batch (src/inverse_cholesky_gpu.cu:
 // 323-354) plus its two gemmBatched calls (src/gauss_bench.cu:210,232) for the sizes its design note calls "512, 1024"
 // (README.md:41-44).
+// (Tried and measured, not kept: ONE cooperative launch for small batches -- the same four bodies looped over by a co-resident
+// grid with cooperative_groups grid.sync() between phases instead of 2 n / PB + 2 dependent launches. 8 x 1024^2 fp32:
+// 5.27 ms against 1.27 ms for the launches; 32 x 512^2: 2.84 against 0.64 ms. A grid-wide barrier over ~500 workgroups costs
+// far more here than the ~6 us gap between two dependent launches.)
 #include "chol_block.hpp"
 
 namespace matinv {
