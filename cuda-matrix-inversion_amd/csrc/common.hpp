@@ -78,6 +78,14 @@ hipError_t launch_gp_rowlane(int n, const T *As, const T *Bs, const T *Cs, const
                              int *info, hipStream_t stream);
 template <class T>
 bool rowlane_family_supports(int n);
+// natural-order pass of the Gauss-Jordan entry point for 16 < n <= 32: the ROWLANE design with two rows per lane
+// (rowlane2_kernels.hip); rejected matrices go to work_list like those of the natural-order tile kernels
+bool rowlane2_supports(int n);
+bool rowlane2_natural_use(bool f64, int n);
+template <class T>
+hipError_t enqueue_gj_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
+                               int *work_list);
+const char *name_gj_rowlane2(bool f64, int n);
 
 // blocked multi-launch Cholesky for the fused GP scalars at large n (blocked_gp_kernels.hip)
 template <class T>

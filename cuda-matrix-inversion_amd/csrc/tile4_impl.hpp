@@ -121,6 +121,9 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
 
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
+            // ragged n: block steps over identity padding only are no-ops (see gj_tile_body); n is workgroup-uniform, so
+            // every wave skips the same (trailing) steps and their barriers
+            if (!FULL && kb > 4 * (NT - 1) && kb - 4 * (NT - 1) >= G::real_blocks(n - 16 * (NT - 1))) continue;
             const int tK = kb >> 2, rK = kb & 3;
             const int owner = tK % T4_WAVES, jo = tK / T4_WAVES;  // wave and local column holding the pivot columns
             const bool panel_lane = G::blk(c) == rK;

@@ -30,6 +30,9 @@ struct TileGeo<double> {
     static __device__ __forceinline__ int piv(int c) { return c & 3; }
     // tile-local column of pivot t in block rK; register / lane group of the tile-local row s (inverse of trow)
     static __device__ __forceinline__ int pcol(int rK, int t) { return 4 * rK + t; }
+    // ragged n: blocks of the LAST tile column that hold at least one real column when rem = n - 16 (NT - 1) of its columns
+    // are real (blocks from this number on are identity padding only and are not run)
+    static __device__ __forceinline__ int real_blocks(int rem) { return (rem + 3) >> 2; }
     static __device__ __forceinline__ int slot_r(int s) { return (s >> 2) & 3; }
     static __device__ __forceinline__ int slot_q(int s) { return s & 3; }
     static __device__ __forceinline__ vec4 mfma(double a, double b, vec4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
@@ -42,6 +45,7 @@ struct TileGeo<float> {
     static __device__ __forceinline__ int blk(int c) { return c & 3; }
     static __device__ __forceinline__ int piv(int c) { return c >> 2; }
     static __device__ __forceinline__ int pcol(int rK, int t) { return 4 * t + rK; }
+    static __device__ __forceinline__ int real_blocks(int rem) { return rem < 4 ? rem : 4; }  // block rK = columns rK, rK + 4, ...
     static __device__ __forceinline__ int slot_r(int s) { return s & 3; }
     static __device__ __forceinline__ int slot_q(int s) { return (s >> 2) & 3; }
     static __device__ __forceinline__ vec4 mfma(float a, float b, vec4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }

@@ -278,9 +278,18 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
             if (w == owner) bop[jo] = panel_lane ? ((G::piv(c) == q) ? (T)1 : (T)0) : bop[jo];
         };
 
+        // ragged n: the all-padding blocks of the last tile column are not run (see tilep_impl.hpp); their table entries keep
+        // the 0xff every wave writes here (before the first turn's barrier, the turns' own entries after it)
+        int last_blocks = 4;
+        if (!FULL) {
+            last_blocks = G::real_blocks(n - 16 * (NT - 1));
+            rowaddr[lr] = coladdr[lr] = (unsigned char)0xff;
+            rowaddr[lr + 64] = coladdr[lr + 64] = (unsigned char)0xff;
+        }
         auto column = [&](auto tKc, int from) {
+            const int to = (decltype(tKc)::value == NT - 1) ? last_blocks : 4;
 #pragma nounroll
-            for (int rK = from; rK < 4; ++rK) turn(tKc, rK, IntC<0>());
+            for (int rK = from; rK < to; ++rK) turn(tKc, rK, IntC<0>());
         };
         turn(IntC<0>(), 0, IntC<1>());
         column(IntC<0>(), 1);

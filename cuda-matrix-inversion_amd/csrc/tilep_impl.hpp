@@ -352,20 +352,28 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
             bop[tKn] = panel_lane ? ((G::piv(c) == q) ? (T)1 : (T)0) : bop[tKn];
         };
 
+        // ragged n: blocks of the last tile column that hold identity padding only are not run. A padding row is zero in
+        // every real column and stays so (it is never a pivot row of one, and elimination adds nothing to it), a padding
+        // column is zero in every real row: such a step changes nothing. Their table entries keep the 0xff written below.
+        int last_blocks = 4;
+        if (!FULL) {
+            last_blocks = G::real_blocks(n - 16 * (NT - 1));
+            if (lr < N) rowaddr[lr] = coladdr[lr] = (unsigned char)0xff;  // >= n: never stored (ordered by the turn's LDS syncs)
+        }
         turn(IntC<0>(), 0, IntC<1>());
 #pragma nounroll
-        for (int rK = 1; rK < 4; ++rK) turn(IntC<0>(), rK, IntC<0>());
+        for (int rK = 1; rK < (NT == 1 ? last_blocks : 4); ++rK) turn(IntC<0>(), rK, IntC<0>());
         if constexpr (NT > 1) {
 #pragma nounroll
-            for (int rK = 0; rK < 4; ++rK) turn(IntC<1>(), rK, IntC<0>());
+            for (int rK = 0; rK < (NT == 2 ? last_blocks : 4); ++rK) turn(IntC<1>(), rK, IntC<0>());
         }
         if constexpr (NT > 2) {
 #pragma nounroll
-            for (int rK = 0; rK < 4; ++rK) turn(IntC<2>(), rK, IntC<0>());
+            for (int rK = 0; rK < (NT == 3 ? last_blocks : 4); ++rK) turn(IntC<2>(), rK, IntC<0>());
         }
         if constexpr (NT > 3) {
 #pragma nounroll
-            for (int rK = 0; rK < 4; ++rK) turn(IntC<3>(), rK, IntC<0>());
+            for (int rK = 0; rK < (NT == 4 ? last_blocks : 4); ++rK) turn(IntC<3>(), rK, IntC<0>());
         }
         // the last block's update
 #pragma unroll

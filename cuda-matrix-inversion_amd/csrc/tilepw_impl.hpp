@@ -267,9 +267,18 @@ __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T
             if (w == tKn) bop = panel_lane ? ((G::piv(c) == q) ? (T)1 : (T)0) : bop;
         };
 
+        // ragged n: the all-padding blocks of the last tile column are not run (see tilep_impl.hpp); their table entries keep
+        // the 0xff written here by wave 0 -- the wave that also writes the first turn's entries, every later turn's owner
+        // writes behind a barrier
+        const int last_blocks = G::real_blocks(nn - 16 * (NT - 1));
+        if (w == 0) {
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) rowaddr[lr + 64 * rr] = coladdr[lr + 64 * rr] = (unsigned char)0xff;
+        }
         auto column = [&](auto tKc, int from) {
+            const int to = (decltype(tKc)::value == NT - 1) ? last_blocks : 4;
 #pragma nounroll
-            for (int rK = from; rK < 4; ++rK) turn(tKc, rK, IntC<0>());
+            for (int rK = from; rK < to; ++rK) turn(tKc, rK, IntC<0>());
         };
         turn(IntC<0>(), 0, IntC<1>());
         column(IntC<0>(), 1);

@@ -153,6 +153,39 @@ def test_square_fixtures_pivoting(f, n, gold):
         assert rel_err(gpu_inverse(a, n, GJ, api.KERNEL_TILEP), gold[f + "/gj"], n) < 1e-10
 
 
+@pytest.mark.parametrize("n", list(range(17, 33)))
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_natural_pass_two_rows_per_lane(n, dtype):
+    """16 < n <= 32: the natural-order pass of the tile family is the two-rows-per-lane kernel where it is the faster one
+    (csrc/rowlane2_kernels.hip). A mixed batch -- SPD matrices it finishes, general ones it must reject for the
+    pivoting kernel, a singular one and one with a NaN -- whose size is not a multiple of the 4 matrices per wavefront."""
+    name = api.kernel_name(GJ, api.F64 if dtype == np.float64 else api.F32, n, api.KERNEL_TILE)
+    assert ("rowlane2" in name) == (n <= 25), name
+    batch = 203
+    a = spd_batch(n, batch, seed=900 + n).reshape(batch, n, n).copy()
+    g = general_batch(n, batch, seed=901 + n).reshape(batch, n, n)
+    a[1::3] = g[1::3]            # every third matrix needs row exchanges
+    a[7, :, n // 2] = 0.0        # memory [k, col, row]: row n/2 of matrix 7 is zero -> singular
+    a[12, 3, 3] = np.nan
+    a = a.astype(dtype)
+    want, winfo = oracle.inverse_batched(a.astype(np.float64).reshape(-1), n, oracle.ALGO_GJ_PIVOT)
+    assert winfo[7] != 0 and winfo[12] != 0 and np.count_nonzero(winfo) == 2
+    for policy_rep in range(3):  # natural order first, then whatever the adaptive dispatch chooses
+        d = dev(a.reshape(-1))  # (not gpu_inverse: its input-unchanged check cannot hold a NaN)
+        dinfo = torch.full((batch,), -7, dtype=torch.int32, device="cuda")
+        got = api.inverse_batched(d, n, GJ, info=dinfo, kernel=api.KERNEL_TILE, batch=batch).cpu().numpy()
+        info = dinfo.cpu().numpy()
+        assert np.array_equal(info != 0, winfo != 0)
+        assert info[7] == winfo[7] and info[12] == winfo[12]
+        gm, wm = as_mats(got.astype(np.float64), n), as_mats(want, n)
+        assert np.isnan(gm[7]).all() and np.isnan(gm[12]).all()
+        ok = winfo == 0
+        cond = max(np.linalg.cond(m) for m in as_mats(a.astype(np.float64).reshape(-1), n)[ok])
+        tol = max(1e-10, 1e-15 * cond * n) if dtype == np.float64 else 2e-6 * cond
+        err = np.abs(gm[ok] - wm[ok]).max(axis=(1, 2)) / np.abs(wm[ok]).max(axis=(1, 2))
+        assert err.max() < tol, (policy_rep, err.max(), tol)
+
+
 @pytest.mark.parametrize("n", [20, 32, 50, 64, 72, 100, 128, 150, 192])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_tile_family_pivots_inside_the_kernel(n, dtype):
