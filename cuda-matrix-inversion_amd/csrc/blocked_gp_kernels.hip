@@ -28,18 +28,36 @@ constexpr int BGP_KS = 32;     // k-slab of the update kernel (LDS staging depth
 constexpr int BGP_TILE = 64;   // update tile edge
 constexpr int BGP_THREADS = 256;
 
-// working copy layout per item: (n + 2) rows x n columns, COLUMN-major with leading dimension ld = n + 2:
+// Leading dimension of a working copy with `rows` rows: padded so that one column is an ODD multiple of 256 bytes. With
+// ld = 2 n = 2048 doubles consecutive columns of a panel are 16 KiB apart and a 64-column panel lands on two of the 128
+// HBM channels; with the odd multiple the columns walk through all of them. MATINV_BGP_PAD=0: unpadded (A/B measurements).
+template <class T>
+__host__ __device__ __forceinline__ int bgp_ld_padded(int rows)
+{
+    int units = (int)(((size_t)rows * sizeof(T) + 255) / 256);
+    units |= 1;
+    return units * (256 / (int)sizeof(T));
+}
+static bool bgp_pad_on()
+{
+    static const bool on = [] { const char *s = getenv("MATINV_BGP_PAD"); return !(s && s[0] == '0'); }();
+    return on;
+}
+template <class T>
+static int bgp_ld(int rows) { return bgp_pad_on() ? bgp_ld_padded<T>(rows) : rows; }
+
+// working copy layout per item: (n + 2) rows x n columns, COLUMN-major with leading dimension ld >= n + 2 (bgp_ld):
 // element (r, c) at c*ld + r; rows n and n+1 are the border rows a^T and d^T (d = a for the variance).
 template <class T>
 __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_init(const T *As, const T *Bs, const T *Cs, const T *Ds, T *W,
-                                                               int n, int *status)
+                                                               int n, int ld, int *status)
 {
     const size_t item = blockIdx.y;
-    const int ld = n + 2;
     T *w = W + item * (size_t)ld * n;
     const T *B = Bs + item * (size_t)n * n;
     for (size_t e = (size_t)blockIdx.x * BGP_THREADS + threadIdx.x; e < (size_t)ld * n; e += (size_t)gridDim.x * BGP_THREADS) {
         const int c = (int)(e / ld), r = (int)(e - (size_t)c * ld);
+        if (r >= n + 2) continue;  // padding of the leading dimension
         T v;
         if (r < n) v = (r >= c) ? B[(size_t)c * n + r] + ((r == c) ? Cs[item * n + c] : (T)0) : (T)0;  // lower triangle only
         else if (r == n) v = As[item * n + c];
@@ -141,13 +159,20 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, in
         }
 }
 
+// (Tried and measured, not kept: both products -- this update and matinv_binv_syrk below -- on the matrix cores, 64 x 64 per
+// workgroup / 32 x 32 per wavefront, computed transposed so that operands and the tile are 128-byte row segments, operands
+// straight from global memory 16 columns ahead of their MFMAs. SPD inverse, fp64, ms per batch, MFMA against these kernels:
+// 256^2 x 3051: 9.7 / 10.7; 512^2 x 762: 16.6 / 16.2; 1024^2 x 256: 38.8 / 32.9; fp32 1024^2: 18.0 / 14.8. With a panel of
+// 64 columns the update is one read-modify-write of the trailing matrix per 64 multiply-adds per element: at the 2.4 TB/s
+// this kernel moves, its flops are not what bounds it, and without LDS staging the operand loads of four independent
+// wavefronts cost more than the matrix cores save. The lever is a wider panel, not the instruction.)
 template <class T>
-__global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_finish(const T *W, const T *Es, T *out, int *info, int n,
+__global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_finish(const T *W, const T *Es, T *out, int *info, int n, int ld,
                                                                  const int *status)
 {
     __shared__ T part[BGP_THREADS / 64];
     const size_t item = blockIdx.x;
-    const int ld = n + 2, t = threadIdx.x;
+    const int t = threadIdx.x;
     const T *w = W + item * (size_t)ld * n;
     const int bad = status[item];
     T s = 0;
@@ -170,7 +195,7 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
 {
     if (n < 1 || n > 4096) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    const int ld = n + 2;
+    const int rows = n + 2, ld = bgp_ld<T>(rows);
     // chunks: grid.y / grid.z limit and a bounded workspace
     size_t chunk = blocked_workspace_cap() / ((size_t)ld * n * sizeof(T));
     if (chunk < 1) chunk = 1;
@@ -185,19 +210,19 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
     for (size_t first = 0; first < batch; first += chunk) {
         const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
         const T *a_ = As + first * n, *B_ = Bs + first * (size_t)n * n, *c_ = Cs + first * n, *d_ = Ds ? Ds + first * n : nullptr;
-        hipLaunchKernelGGL(matinv_bgp_init<T>, dim3(64, b), dim3(BGP_THREADS), 0, stream, a_, B_, c_, d_, W, n, status);
+        hipLaunchKernelGGL(matinv_bgp_init<T>, dim3(64, b), dim3(BGP_THREADS), 0, stream, a_, B_, c_, d_, W, n, ld, status);
         for (int k0 = 0; k0 < n; k0 += BGP_PB) {
             const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
-            const unsigned chunks = (unsigned)((ld - (k0 + pb) + BGP_THREADS - 1) / BGP_THREADS);  // >= 1: the border rows
-            hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, n, ld, ld, k0, status);
-            const int rem_cols = n - (k0 + BGP_PB), rem_rows = ld - (k0 + BGP_PB);
+            const unsigned chunks = (unsigned)((rows - (k0 + pb) + BGP_THREADS - 1) / BGP_THREADS);  // >= 1: the border rows
+            hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, n, ld, rows, k0, status);
+            const int rem_cols = n - (k0 + BGP_PB), rem_rows = rows - (k0 + BGP_PB);
             if (rem_cols > 0) {
                 const unsigned gx = (rem_cols + BGP_TILE - 1) / BGP_TILE, gy = (rem_rows + BGP_TILE - 1) / BGP_TILE;
-                hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, b), dim3(BGP_THREADS), 0, stream, W, n, ld, ld, k0, status);
+                hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, b), dim3(BGP_THREADS), 0, stream, W, n, ld, rows, k0, status);
             }
         }
         hipLaunchKernelGGL(matinv_bgp_finish<T>, dim3(b), dim3(BGP_THREADS), 0, stream, W, (Ds || !Es) ? nullptr : Es + first,
-                           out + first, info ? info + first : nullptr, n, status);
+                           out + first, info ? info + first : nullptr, n, ld, status);
     }
     e = hipGetLastError();
     hipError_t e2 = hipFreeAsync(W, stream), e3 = hipFreeAsync(status, stream);
@@ -216,14 +241,14 @@ template hipError_t launch_gp_blocked<float>(int, const float *, const float *, 
 // n^3/3 flops each for the factor, the triangular inverse and the product -- the three phases of
 // /root/reference/src/inverse_cholesky_cpu.c:17-85 in blocked form. Only the lower triangle of A is read.
 template <class T>
-__global__ __launch_bounds__(BGP_THREADS) void matinv_binv_init(BatchRef<const T> Ain, size_t first, T *W, int n, int *status)
+__global__ __launch_bounds__(BGP_THREADS) void matinv_binv_init(BatchRef<const T> Ain, size_t first, T *W, int n, int ld, int *status)
 {
     const size_t item = blockIdx.y;
-    const int ld = 2 * n;
     T *w = W + item * (size_t)ld * n;
     const T *A = Ain.at(first + item);
     for (size_t e = (size_t)blockIdx.x * BGP_THREADS + threadIdx.x; e < (size_t)ld * n; e += (size_t)gridDim.x * BGP_THREADS) {
         const int c = (int)(e / ld), r = (int)(e - (size_t)c * ld);
+        if (r >= 2 * n) continue;  // padding of the leading dimension
         w[e] = (r < n) ? ((r >= c) ? A[(size_t)c * n + r] : (T)0) : ((r - n == c) ? (T)1 : (T)0);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) status[item] = 0;
@@ -232,13 +257,13 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_binv_init(BatchRef<const T
 // X[i][j] = sum_{c >= max(i,j)} Y[i][c] Y[j][c]; one workgroup per 64 x 64 tile with j0 <= i0, mirrored on write
 template <class T>
 __global__ __launch_bounds__(BGP_THREADS) void matinv_binv_syrk(const T *W, BatchRef<T> Xout, size_t first, int *info, int n,
-                                                                const int *status)
+                                                                int ld, const int *status)
 {
     __shared__ T Yi[BGP_KS][BGP_TILE + 1], Yj[BGP_KS][BGP_TILE + 1];
     const size_t item = blockIdx.z;
     const int j0 = blockIdx.x * BGP_TILE, i0 = blockIdx.y * BGP_TILE;
     if (j0 > i0) return;
-    const int ld = 2 * n, t = threadIdx.x;
+    const int t = threadIdx.x;
     const T *w = W + item * (size_t)ld * n;
     T *X = Xout.at(first + item);
     const int bad = status[item];
@@ -286,8 +311,8 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 {
     if (!blocked_inverse_supports(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    const int ld = 2 * n;
-    // chunks: grid.y / grid.z limit and a bounded workspace (<= 4 GiB)
+    const int ld = bgp_ld<T>(2 * n);
+    // chunks: grid.y / grid.z limit and a bounded workspace
     size_t chunk = blocked_workspace_cap() / ((size_t)ld * n * sizeof(T));
     if (chunk < 1) chunk = 1;
     if (chunk > 65535) chunk = 65535;
@@ -300,7 +325,7 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     if (e != hipSuccess) { (void)hipFreeAsync(W, stream); return e; }
     for (size_t first = 0; first < batch; first += chunk) {
         const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
-        hipLaunchKernelGGL(matinv_binv_init<T>, dim3(64, b), dim3(BGP_THREADS), 0, stream, A, first, W, n, status);
+        hipLaunchKernelGGL(matinv_binv_init<T>, dim3(64, b), dim3(BGP_THREADS), 0, stream, A, first, W, n, ld, status);
         for (int k0 = 0; k0 < n; k0 += BGP_PB) {
             const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
             const int row_end = n + k0 + pb;  // border rows beyond it are still zero in these columns
@@ -313,7 +338,7 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
             }
         }
         const unsigned g = (unsigned)((n + BGP_TILE - 1) / BGP_TILE);
-        hipLaunchKernelGGL(matinv_binv_syrk<T>, dim3(g, g, b), dim3(BGP_THREADS), 0, stream, W, X, first, info, n, status);
+        hipLaunchKernelGGL(matinv_binv_syrk<T>, dim3(g, g, b), dim3(BGP_THREADS), 0, stream, W, X, first, info, n, ld, status);
     }
     e = hipGetLastError();
     hipError_t e2 = hipFreeAsync(W, stream), e3 = hipFreeAsync(status, stream);
