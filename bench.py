@@ -41,6 +41,8 @@ WORKLOADS = {
     "gj16": (16, "gj", "batch x 16x16 fp64 Gauss-Jordan (threshold partial pivoting), SPD inputs, BASELINE configs[1]"),
     "gj32": (32, "gj", "batch x 32x32 fp64 Gauss-Jordan"),
     "gj8": (8, "gj", "batch x 8x8 fp64 Gauss-Jordan"),
+    "gj24": (24, "gj", "batch x 24x24 fp64 Gauss-Jordan (two rows per lane, DPP broadcasts; natural-order pivots verified), SPD inputs"),
+    "gj50": (50, "gj", "batch x 50x50 fp64 Gauss-Jordan (ragged: 4 x 4 MFMA tiles, 13 of 16 block steps), SPD inputs"),
     "gj128": (128, "gj", "batch x 128x128 fp64 Gauss-Jordan"),
     # GENERAL input: A ~ U(0,1)^(n x n), not symmetric, not dominant (like the reference's tests/square_5_*.mats): every
     # matrix needs row exchanges
@@ -421,7 +423,7 @@ def main():
         # the other single-GPU workloads, a few launches each (same timing method), so that every path -- the weak ones
         # included -- is driver-timed each round
         del a, x
-        for wname in ("gj16", "chol64", "gj32", "gj8", "gj128", "gj64g", "gj32g", "gj128g", "gj192g", "chol192", "gj256g", "chol256",
+        for wname in ("gj16", "chol64", "gj32", "gj24", "gj50", "gj8", "gj128", "gj64g", "gj32g", "gj128g", "gj192g", "chol192", "gj256g", "chol256",
                       "gj1024g"):
             if wname == args.workload:
                 continue

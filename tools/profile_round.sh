@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $W -o trace -- python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench_default.json 2> $W/trace.err
 python3 $R/tools/rocprof_summary.py $W/trace_results.db "$TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3" > $OUT/${TAG}_bench_default_kernel_trace.txt
 
-for w in gj64 gj16 chol64 gj128 gj64g gj32g gj128g; do
+for w in gj64 gj16 gj24 chol64 gj128 gj64g gj32g gj128g; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c -d $W -o ${w}_$c -- python3 $R/bench.py --workload $w --steps 3 --warmup 2 --no-cpu-baseline --no-others > $W/${w}_$c.out 2>&1
   done
