@@ -54,6 +54,7 @@ WORKLOADS = {
     "gj256g": (256, "gj", "batch x 256x256 fp64 blocked Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
     "gj1024g": (1024, "gj", "batch x 1024x1024 fp64 blocked Gauss-Jordan (two-level, MFMA update), GENERAL U(0,1) inputs"),
     "chol256": (256, "chol", "batch x 256x256 fp64 blocked Cholesky inverse, SPD inputs"),
+    "chol1024": (1024, "chol", "batch x 1024x1024 fp64 blocked Cholesky inverse (panel pairs, rank-128 update, Y Y^T product), SPD inputs"),
 }
 GENERAL = {"gj64g", "gj32g", "gj128g", "gj192g", "gj256g", "gj1024g"}
 

@@ -20,6 +20,7 @@
 // 5.27 ms against 1.27 ms for the launches; 32 x 512^2: 2.84 against 0.64 ms. A grid-wide barrier over ~500 workgroups costs
 // far more here than the ~6 us gap between two dependent launches.)
 #include "chol_block.hpp"
+#include "tile_common.hpp"
 
 namespace matinv {
 
@@ -27,6 +28,7 @@ constexpr int BGP_PB = 64;     // panel width
 constexpr int BGP_KS = 32;     // k-slab of the update kernel (LDS staging depth)
 constexpr int BGP_TILE = 64;   // update tile edge
 constexpr int BGP_THREADS = 256;
+constexpr int BGP_LDS = 80;    // row stride of the LDS slabs [k][row]: the four k-groups of an MFMA operand read land in disjoint banks
 
 // Leading dimension of a working copy with `rows` rows: padded so that one column is an ODD multiple of 256 bytes. With
 // ld = 2 n = 2048 doubles consecutive columns of a panel are 16 KiB apart and a 64-column panel lands on two of the 128
@@ -117,46 +119,86 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_panel(T *W, int n, int
         if (c < pb) w[(size_t)(k0 + c) * ld + r] = x[c];
 }
 
-// trailing update: W[I, J] -= L[I, K] L[J, K]^T for 64 x 64 tiles with J >= k0 + pb, I >= J (rows up to n + 1)
+// One slab (BGP_KS columns, staged in LDS as S[k][row]) of the 64 x 64 tile product D[J, I] += sum_k Sj[k][J] Si[k][I] on the matrix
+// cores: wavefront wv owns the 32 x 32 part (J half wv >> 1, I half wv & 1) as 2 x 2 MFMA tiles. The tile is computed TRANSPOSED
+// (the MFMA's A operand carries the J side): in the accumulator layout the 16 lanes of a group then hold 16 consecutive ROWS I
+// of one column J -- the contiguous direction of the column-major working copy, so the tile itself is read and written in
+// 128-byte segments. Per 4 columns a wavefront reads 4 x 512 B from LDS for 4 MFMAs; the 4 x 4-per-thread vector-ALU form this
+// replaces read 4 KB per 16 FMAs and spent its time on the LDS (PMC, SPD inverse 1024^2: 52 % of the LDS cycles bank conflicts,
+// vector ALU 10 % busy).
 template <class T>
-__global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, int ld, int row_end, int k0, const int *status)
+__device__ __forceinline__ void bgp_slab_mma(const T (*Sj)[BGP_LDS], const T (*Si)[BGP_LDS], int wv, int q, int c,
+                                             typename TileGeo<T>::vec4 (&acc)[2][2])
 {
-    __shared__ T Li[BGP_KS][BGP_TILE + 1], Lj[BGP_KS][BGP_TILE + 1];
+    typedef TileGeo<T> G;
+    const int jb = 32 * (wv >> 1) + c, ib = 32 * (wv & 1) + c;
+#pragma unroll
+    for (int k4 = 0; k4 < BGP_KS; k4 += 4) {  // columns beyond the slab's kd are zero-filled by the fetch
+        const T a0 = Sj[k4 + q][jb], a1 = Sj[k4 + q][jb + 16], b0 = Si[k4 + q][ib], b1 = Si[k4 + q][ib + 16];
+        acc[0][0] = G::mfma(a0, b0, acc[0][0]);
+        acc[0][1] = G::mfma(a0, b1, acc[0][1]);
+        acc[1][0] = G::mfma(a1, b0, acc[1][0]);
+        acc[1][1] = G::mfma(a1, b1, acc[1][1]);
+    }
+}
+
+// trailing update: W[I, J] -= L[I, K] L[J, K]^T for 64 x 64 tiles with jbeg <= J < jend, I >= J (rows up to row_end - 1);
+// K = the kcnt panel columns from kbeg on (one panel of 64, or the two panels of a pair: see launch_gp_blocked)
+template <class T>
+__global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, int ld, int row_end, int kbeg, int kcnt, int jbeg,
+                                                                 int jend, const int *status)
+{
+    typedef TileGeo<T> G;
+    __shared__ T Li[BGP_KS][BGP_LDS], Lj[BGP_KS][BGP_LDS];
     const size_t item = blockIdx.z;
     if (status[item] != 0) return;
-    const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
-    const int j0 = k0 + pb + blockIdx.x * BGP_TILE, i0 = k0 + pb + blockIdx.y * BGP_TILE;
-    if (j0 >= n || i0 >= row_end || i0 + BGP_TILE <= j0) return;  // outside, or strictly above the diagonal
+    const int pb = kcnt, k0 = kbeg;
+    const int j0 = jbeg + blockIdx.x * BGP_TILE, i0 = jbeg + blockIdx.y * BGP_TILE;
+    if (j0 >= jend || i0 >= row_end || i0 + BGP_TILE <= j0) return;  // outside, or strictly above the diagonal
     T *w = W + item * (size_t)ld * n;
-    const int t = threadIdx.x;
-    const int ti = (t & 15) * 4, tj = (t >> 4) * 4;  // 4 x 4 outputs per thread: rows i0+ti.., columns j0+tj..
-    T acc[4][4] = {};
+    const int t = threadIdx.x, wv = t >> 6, q = (t >> 4) & 3, c = t & 15;
+    // this wavefront's 32 x 32 part strictly above the diagonal: it only helps staging (wave-uniform)
+    const bool live = i0 + 32 * (wv & 1) + 32 > j0 + 32 * (wv >> 1);
+    typename G::vec4 acc[2][2] = {};
+    // slabs of BGP_KS panel columns through LDS; the NEXT slab is fetched into registers while the current one is multiplied
+    // (thread t fetches row t & 63 of columns (t >> 6) + 4 x; clamped addresses, so the loads are unconditional)
+    const int lr = t & 63, lk = t >> 6;
+    const bool in_i = i0 + lr < row_end, in_j = j0 + lr < jend;
+    const T *wi = w + (in_i ? i0 + lr : row_end - 1), *wj = w + (in_j ? j0 + lr : jend - 1);
+    T pi[BGP_KS / 4], pj[BGP_KS / 4];
+    auto fetch = [&](int ks) {
+#pragma unroll
+        for (int x = 0; x < BGP_KS / 4; ++x) {
+            const int k = ks + lk + 4 * x;
+            const bool kin = k < pb;
+            const size_t col = (size_t)(k0 + (kin ? k : pb - 1)) * ld;
+            const T vi = wi[col], vj = wj[col];
+            pi[x] = (kin && in_i) ? vi : (T)0;
+            pj[x] = (kin && in_j) ? vj : (T)0;
+        }
+    };
+    fetch(0);
     for (int ks = 0; ks < pb; ks += BGP_KS) {
-        const int kd = (pb - ks < BGP_KS) ? pb - ks : BGP_KS;
         __syncthreads();
-        for (int e = t; e < kd * BGP_TILE; e += BGP_THREADS) {
-            const int k = e / BGP_TILE, r = e - k * BGP_TILE;
-            Li[k][r] = (i0 + r < row_end) ? w[(size_t)(k0 + ks + k) * ld + i0 + r] : (T)0;
-            Lj[k][r] = (j0 + r < n) ? w[(size_t)(k0 + ks + k) * ld + j0 + r] : (T)0;
+#pragma unroll
+        for (int x = 0; x < BGP_KS / 4; ++x) {
+            Li[lk + 4 * x][lr] = pi[x];
+            Lj[lk + 4 * x][lr] = pj[x];
         }
         __syncthreads();
-        for (int k = 0; k < kd; ++k) {
-            T a[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = Li[k][ti + u]; b[u] = Lj[k][tj + u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
-        }
+        if (ks + BGP_KS < pb) fetch(ks + BGP_KS);
+        if (live) bgp_slab_mma<T>(Lj, Li, wv, q, c, acc);
     }
+    if (!live) return;
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
+    for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = i0 + ti + u, c = j0 + tj + v;
-            if (r < row_end && c < n && r >= c) w[(size_t)c * ld + r] -= acc[u][v];
-        }
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int J = j0 + 32 * (wv >> 1) + 16 * tj + G::trow(r, q), I = i0 + 32 * (wv & 1) + 16 * ti + c;
+                if (I < row_end && J < jend && I >= J) w[(size_t)J * ld + I] -= acc[tj][ti][r];
+            }
 }
 
 // (Tried and measured, not kept: both products -- this update and matinv_binv_syrk below -- on the matrix cores, 64 x 64 per
@@ -189,6 +231,46 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_finish(const T *W, con
     }
 }
 
+// one PAIR of 64-column panels starting at column k0 (the second one may be ragged or absent); rows1 / rows2 = number of rows
+// the first / second panel's columns can be non-zero in
+// Pairs pay when the update launches are throughput-bound (fused pipeline 256 x 1024^2 fp32: 5.35 -> 4.59 ms, 762 x 512^2: 2.84 ->
+// 2.47 ms); a handful of items (the 8-item bins of the mixed queue) is bound by the dependent-launch chain, where the longer
+// rank-128 tiles cost 3 %: those keep one update per panel.
+static bool bgp_pairs_pay(int n, unsigned b)
+{
+    const size_t nt = (size_t)(n + BGP_TILE - 1) / BGP_TILE;
+    return (size_t)b * nt * nt / 2 >= 4096;
+}
+
+template <class T>
+static void bgp_pair(T *W, int n, int ld, int k0, int rows1, int rows2, unsigned b, int *status, hipStream_t stream)
+{
+    auto panel = [&](int kb, int rows_) {
+        const int pb = (n - kb < BGP_PB) ? n - kb : BGP_PB;
+        const unsigned chunks = (unsigned)((rows_ - (kb + pb) + BGP_THREADS - 1) / BGP_THREADS);  // >= 1: the border rows
+        hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, n, ld, rows_, kb, status);
+    };
+    auto update = [&](int kcnt, int jbeg, int jend, int rows_) {
+        const unsigned gx = (unsigned)((jend - jbeg + BGP_TILE - 1) / BGP_TILE), gy = (unsigned)((rows_ - jbeg + BGP_TILE - 1) / BGP_TILE);
+        hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, b), dim3(BGP_THREADS), 0, stream, W, n, ld, rows_, k0, kcnt, jbeg, jend,
+                           status);
+    };
+    panel(k0, rows1);
+    const int k1 = k0 + BGP_PB;
+    if (k1 >= n) return;
+    const int k2 = (k1 + BGP_PB < n) ? k1 + BGP_PB : n;
+    if (!bgp_pairs_pay(n, b)) {  // one update per panel
+        update(BGP_PB, k1, n, rows1);
+        k0 = k1;
+        panel(k1, rows2);
+        if (k2 < n) update(k2 - k1, k2, n, rows2);
+        return;
+    }
+    update(BGP_PB, k1, k2, rows1);  // narrow: the columns of the second panel
+    panel(k1, rows2);
+    if (k2 < n) update(k2 - k0, k2, n, rows2);  // wide: both panels at once
+}
+
 template <class T>
 hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
                              int *info, hipStream_t stream)
@@ -211,15 +293,11 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
         const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
         const T *a_ = As + first * n, *B_ = Bs + first * (size_t)n * n, *c_ = Cs + first * n, *d_ = Ds ? Ds + first * n : nullptr;
         hipLaunchKernelGGL(matinv_bgp_init<T>, dim3(64, b), dim3(BGP_THREADS), 0, stream, a_, B_, c_, d_, W, n, ld, status);
-        for (int k0 = 0; k0 < n; k0 += BGP_PB) {
-            const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
-            const unsigned chunks = (unsigned)((rows - (k0 + pb) + BGP_THREADS - 1) / BGP_THREADS);  // >= 1: the border rows
-            hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, n, ld, rows, k0, status);
-            const int rem_cols = n - (k0 + BGP_PB), rem_rows = rows - (k0 + BGP_PB);
-            if (rem_cols > 0) {
-                const unsigned gx = (rem_cols + BGP_TILE - 1) / BGP_TILE, gy = (rem_rows + BGP_TILE - 1) / BGP_TILE;
-                hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, b), dim3(BGP_THREADS), 0, stream, W, n, ld, rows, k0, status);
-            }
+        // Panels of 64 columns applied in PAIRS: after the first panel only the next 64 columns are updated (narrow launch),
+        // the second panel is factored, and everything behind the pair takes both panels in ONE rank-128 update -- the same
+        // number of launches as panel / update per 64 columns, half the read-modify-write traffic on the trailing matrix.
+        for (int k0 = 0; k0 < n; k0 += 2 * BGP_PB) {
+            bgp_pair<T>(W, n, ld, k0, rows, rows, b, status, stream);
         }
         hipLaunchKernelGGL(matinv_bgp_finish<T>, dim3(b), dim3(BGP_THREADS), 0, stream, W, (Ds || !Es) ? nullptr : Es + first,
                            out + first, info ? info + first : nullptr, n, ld, status);
@@ -259,48 +337,59 @@ template <class T>
 __global__ __launch_bounds__(BGP_THREADS) void matinv_binv_syrk(const T *W, BatchRef<T> Xout, size_t first, int *info, int n,
                                                                 int ld, const int *status)
 {
-    __shared__ T Yi[BGP_KS][BGP_TILE + 1], Yj[BGP_KS][BGP_TILE + 1];
+    typedef TileGeo<T> G;
+    __shared__ T Yi[BGP_KS][BGP_LDS], Yj[BGP_KS][BGP_LDS];
     const size_t item = blockIdx.z;
     const int j0 = blockIdx.x * BGP_TILE, i0 = blockIdx.y * BGP_TILE;
     if (j0 > i0) return;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, wv = t >> 6, q = (t >> 4) & 3, c = t & 15;
     const T *w = W + item * (size_t)ld * n;
     T *X = Xout.at(first + item);
     const int bad = status[item];
-    const int ti = (t & 15) * 4, tj = (t >> 4) * 4;
-    T acc[4][4] = {};
-    if (!bad) {
+    typename G::vec4 acc[2][2] = {};
+    if (!bad) {  // block-uniform
+        // as in matinv_bgp_update: the next slab of 32 columns is fetched into registers while the current one is multiplied
+        const int lr = t & 63, lk = t >> 6;
+        const bool in_i = i0 + lr < n, in_j = j0 + lr < n;
+        const T *wi = w + n + (in_i ? i0 + lr : n - 1), *wj = w + n + (in_j ? j0 + lr : n - 1);
+        T pi[BGP_KS / 4], pj[BGP_KS / 4];
+        auto fetch = [&](int c0) {
+#pragma unroll
+            for (int x = 0; x < BGP_KS / 4; ++x) {
+                const int cc = c0 + lk + 4 * x;
+                const bool cin = cc < n;
+                const size_t col = (size_t)(cin ? cc : n - 1) * ld;
+                const T vi = wi[col], vj = wj[col];
+                pi[x] = (cin && in_i) ? vi : (T)0;
+                pj[x] = (cin && in_j) ? vj : (T)0;
+            }
+        };
+        fetch(i0);
         for (int c0 = i0; c0 < n; c0 += BGP_KS) {  // Y[i][c] = 0 for c < i: start at the tile's first row
-            const int kd = (n - c0 < BGP_KS) ? n - c0 : BGP_KS;
             __syncthreads();
-            for (int e = t; e < kd * BGP_TILE; e += BGP_THREADS) {
-                const int k = e / BGP_TILE, r = e - k * BGP_TILE;
-                Yi[k][r] = (i0 + r < n) ? w[(size_t)(c0 + k) * ld + n + i0 + r] : (T)0;
-                Yj[k][r] = (j0 + r < n) ? w[(size_t)(c0 + k) * ld + n + j0 + r] : (T)0;
+#pragma unroll
+            for (int x = 0; x < BGP_KS / 4; ++x) {
+                Yi[lk + 4 * x][lr] = pi[x];
+                Yj[lk + 4 * x][lr] = pj[x];
             }
             __syncthreads();
-            for (int k = 0; k < kd; ++k) {
-                T a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { a[u] = Yi[k][ti + u]; b[u] = Yj[k][tj + u]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
-            }
+            if (c0 + BGP_KS < n) fetch(c0 + BGP_KS);
+            bgp_slab_mma<T>(Yj, Yi, wv, q, c, acc);
         }
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
+    for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + ti + u, j = j0 + tj + v;
-            if (i < n && j < n) {
-                const T x = bad ? nan_of<T>() : acc[u][v];
-                X[(size_t)j * n + i] = x;
-                if (i0 != j0) X[(size_t)i * n + j] = x;  // off-diagonal tiles fill their mirror image
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int J = j0 + 32 * (wv >> 1) + 16 * tj + G::trow(r, q), I = i0 + 32 * (wv & 1) + 16 * ti + c;
+                if (I < n && J < n) {
+                    const T x = bad ? nan_of<T>() : acc[tj][ti][r];
+                    X[(size_t)J * n + I] = x;
+                    if (i0 != j0) X[(size_t)I * n + J] = x;  // off-diagonal tiles fill their mirror image
+                }
             }
-        }
     if (info && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) info[first + item] = bad;
 }
 
@@ -326,16 +415,10 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     for (size_t first = 0; first < batch; first += chunk) {
         const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
         hipLaunchKernelGGL(matinv_binv_init<T>, dim3(64, b), dim3(BGP_THREADS), 0, stream, A, first, W, n, ld, status);
-        for (int k0 = 0; k0 < n; k0 += BGP_PB) {
-            const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
-            const int row_end = n + k0 + pb;  // border rows beyond it are still zero in these columns
-            const unsigned chunks = (unsigned)((row_end - (k0 + pb) + BGP_THREADS - 1) / BGP_THREADS);
-            hipLaunchKernelGGL(matinv_bgp_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, n, ld, row_end, k0, status);
-            const int rem_cols = n - (k0 + BGP_PB), rem_rows = row_end - (k0 + BGP_PB);
-            if (rem_cols > 0) {
-                const unsigned gx = (rem_cols + BGP_TILE - 1) / BGP_TILE, gy = (rem_rows + BGP_TILE - 1) / BGP_TILE;
-                hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(gx, gy, b), dim3(BGP_THREADS), 0, stream, W, n, ld, row_end, k0, status);
-            }
+        // border rows beyond n + (end of a panel) are still zero in that panel's columns: each launch stops there
+        for (int k0 = 0; k0 < n; k0 += 2 * BGP_PB) {
+            const int e1 = (k0 + BGP_PB < n) ? k0 + BGP_PB : n, e2 = (k0 + 2 * BGP_PB < n) ? k0 + 2 * BGP_PB : n;
+            bgp_pair<T>(W, n, ld, k0, n + e1, n + e2, b, status, stream);
         }
         const unsigned g = (unsigned)((n + BGP_TILE - 1) / BGP_TILE);
         hipLaunchKernelGGL(matinv_binv_syrk<T>, dim3(g, g, b), dim3(BGP_THREADS), 0, stream, W, X, first, info, n, ld, status);
