@@ -20,7 +20,7 @@
 // 5.27 ms against 1.27 ms for the launches; 32 x 512^2: 2.84 against 0.64 ms. A grid-wide barrier over ~500 workgroups costs
 // far more here than the ~6 us gap between two dependent launches.)
 #include "chol_block.hpp"
-#include "tile_common.hpp"
+#include "slab_mma.hpp"
 
 namespace matinv {
 
@@ -28,7 +28,8 @@ constexpr int BGP_PB = 64;     // panel width
 constexpr int BGP_KS = 32;     // k-slab of the update kernel (LDS staging depth)
 constexpr int BGP_TILE = 64;   // update tile edge
 constexpr int BGP_THREADS = 256;
-constexpr int BGP_LDS = 80;    // row stride of the LDS slabs [k][row]: the four k-groups of an MFMA operand read land in disjoint banks
+constexpr int BGP_LDS = SLAB_LDS;  // row stride of the LDS slabs [k][row] (slab_mma.hpp)
+static_assert(BGP_KS == SLAB_KS, "the update and product kernels stage slab_mma's slabs");
 
 // Leading dimension of a working copy with `rows` rows: padded so that one column is an ODD multiple of 256 bytes. With
 // ld = 2 n = 2048 doubles consecutive columns of a panel are 16 KiB apart and a 64-column panel lands on two of the 128
@@ -119,29 +120,6 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_panel(T *W, int n, int
         if (c < pb) w[(size_t)(k0 + c) * ld + r] = x[c];
 }
 
-// One slab (BGP_KS columns, staged in LDS as S[k][row]) of the 64 x 64 tile product D[J, I] += sum_k Sj[k][J] Si[k][I] on the matrix
-// cores: wavefront wv owns the 32 x 32 part (J half wv >> 1, I half wv & 1) as 2 x 2 MFMA tiles. The tile is computed TRANSPOSED
-// (the MFMA's A operand carries the J side): in the accumulator layout the 16 lanes of a group then hold 16 consecutive ROWS I
-// of one column J -- the contiguous direction of the column-major working copy, so the tile itself is read and written in
-// 128-byte segments. Per 4 columns a wavefront reads 4 x 512 B from LDS for 4 MFMAs; the 4 x 4-per-thread vector-ALU form this
-// replaces read 4 KB per 16 FMAs and spent its time on the LDS (PMC, SPD inverse 1024^2: 52 % of the LDS cycles bank conflicts,
-// vector ALU 10 % busy).
-template <class T>
-__device__ __forceinline__ void bgp_slab_mma(const T (*Sj)[BGP_LDS], const T (*Si)[BGP_LDS], int wv, int q, int c,
-                                             typename TileGeo<T>::vec4 (&acc)[2][2])
-{
-    typedef TileGeo<T> G;
-    const int jb = 32 * (wv >> 1) + c, ib = 32 * (wv & 1) + c;
-#pragma unroll
-    for (int k4 = 0; k4 < BGP_KS; k4 += 4) {  // columns beyond the slab's kd are zero-filled by the fetch
-        const T a0 = Sj[k4 + q][jb], a1 = Sj[k4 + q][jb + 16], b0 = Si[k4 + q][ib], b1 = Si[k4 + q][ib + 16];
-        acc[0][0] = G::mfma(a0, b0, acc[0][0]);
-        acc[0][1] = G::mfma(a0, b1, acc[0][1]);
-        acc[1][0] = G::mfma(a1, b0, acc[1][0]);
-        acc[1][1] = G::mfma(a1, b1, acc[1][1]);
-    }
-}
-
 // trailing update: W[I, J] -= L[I, K] L[J, K]^T for 64 x 64 tiles with jbeg <= J < jend, I >= J (rows up to row_end - 1);
 // K = the kcnt panel columns from kbeg on (one panel of 64, or the two panels of a pair: see launch_gp_blocked)
 template <class T>
@@ -188,7 +166,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, in
         }
         __syncthreads();
         if (ks + BGP_KS < pb) fetch(ks + BGP_KS);
-        if (live) bgp_slab_mma<T>(Lj, Li, wv, q, c, acc);
+        if (live) slab_mma<T>(Lj, Li, wv, q, c, acc);
     }
     if (!live) return;
 #pragma unroll
@@ -375,7 +353,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_binv_syrk(const T *W, Batc
             }
             __syncthreads();
             if (c0 + BGP_KS < n) fetch(c0 + BGP_KS);
-            bgp_slab_mma<T>(Yj, Yi, wv, q, c, acc);
+            slab_mma<T>(Yj, Yi, wv, q, c, acc);
         }
     }
 #pragma unroll
