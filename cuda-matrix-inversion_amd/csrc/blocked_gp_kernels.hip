@@ -25,7 +25,7 @@
 namespace matinv {
 
 constexpr int BGP_PB = 64;     // panel width
-constexpr int BGP_KS = 32;     // k-slab of the update kernel (LDS staging depth)
+constexpr int BGP_KS = 16;     // k-slab of the update kernel (LDS staging depth)
 constexpr int BGP_TILE = 64;   // update tile edge
 constexpr int BGP_THREADS = 256;
 constexpr int BGP_LDS = SLAB_LDS;  // row stride of the LDS slabs [k][row] (slab_mma.hpp)
@@ -151,9 +151,8 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, in
             const int k = ks + lk + 4 * x;
             const bool kin = k < pb;
             const size_t col = (size_t)(k0 + (kin ? k : pb - 1)) * ld;
-            const T vi = wi[col], vj = wj[col];
-            pi[x] = (kin && in_i) ? vi : (T)0;
-            pj[x] = (kin && in_j) ? vj : (T)0;
+            pi[x] = wi[col];  // raw: padding is zeroed when the slab is staged -- a select here would make the wave wait
+            pj[x] = wj[col];  // for the loads before the MFMAs they are meant to hide behind
         }
     };
     fetch(0);
@@ -161,8 +160,9 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, in
         __syncthreads();
 #pragma unroll
         for (int x = 0; x < BGP_KS / 4; ++x) {
-            Li[lk + 4 * x][lr] = pi[x];
-            Lj[lk + 4 * x][lr] = pj[x];
+            const bool kin = ks + lk + 4 * x < pb;
+            Li[lk + 4 * x][lr] = (kin && in_i) ? pi[x] : (T)0;
+            Lj[lk + 4 * x][lr] = (kin && in_j) ? pj[x] : (T)0;
         }
         __syncthreads();
         if (ks + BGP_KS < pb) fetch(ks + BGP_KS);
@@ -338,9 +338,8 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_binv_syrk(const T *W, Batc
                 const int cc = c0 + lk + 4 * x;
                 const bool cin = cc < n;
                 const size_t col = (size_t)(cin ? cc : n - 1) * ld;
-                const T vi = wi[col], vj = wj[col];
-                pi[x] = (cin && in_i) ? vi : (T)0;
-                pj[x] = (cin && in_j) ? vj : (T)0;
+                pi[x] = wi[col];  // raw; zeroed when staged (see matinv_bgp_update)
+                pj[x] = wj[col];
             }
         };
         fetch(i0);
@@ -348,8 +347,9 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_binv_syrk(const T *W, Batc
             __syncthreads();
 #pragma unroll
             for (int x = 0; x < BGP_KS / 4; ++x) {
-                Yi[lk + 4 * x][lr] = pi[x];
-                Yj[lk + 4 * x][lr] = pj[x];
+                const bool cin = c0 + lk + 4 * x < n;
+                Yi[lk + 4 * x][lr] = (cin && in_i) ? pi[x] : (T)0;
+                Yj[lk + 4 * x][lr] = (cin && in_j) ? pj[x] : (T)0;
             }
             __syncthreads();
             if (c0 + BGP_KS < n) fetch(c0 + BGP_KS);
