@@ -364,7 +364,11 @@ __global__ __launch_bounds__(256) void matinv_bgj_update_mfma(const T *Xold, siz
     constexpr int WT = 16 * MT, TS = 2 * WT;   // wave tile, workgroup tile
     constexpr int KS = MT == 4 ? 16 : 32;      // slab depth
     constexpr int PER = KS * TS / 256;         // slab elements per thread and operand
-    __shared__ T Gt[KS][TS], Bt[KS][TS];
+    // fp32: row stride TS + 16, so that the four k-groups of an MFMA operand read (rows k .. k+3, 16 consecutive elements each)
+    // land in disjoint LDS banks (1024^2 x 256: 19.6 -> 18.5 ms). fp64 keeps stride TS: the padded slabs (41 KB) cost a
+    // workgroup per CU, which outweighs the conflicts there (31.3 ms unpadded, 31.8 padded).
+    constexpr int LDS_ROW = TS + (sizeof(T) == 8 ? 0 : 16);
+    __shared__ T Gt[KS][LDS_ROW], Bt[KS][LDS_ROW];
     __shared__ int rsrc[TS];
     const size_t item = blockIdx.z;
     if (status[item] != 0) return;
@@ -384,12 +388,16 @@ __global__ __launch_bounds__(256) void matinv_bgj_update_mfma(const T *Xold, siz
     vec4 acc[MT][MT] = {};
     if (!all_skipped) {
         T gq[PER], bq[PER];
+        // The prefetch is RAW (addresses clamped into the operands, so the loads are unconditional); padding is zeroed when
+        // the slab is staged. Written as `in ? load : 0` the select sits right behind the loads and the wave waits for them
+        // before the MFMAs they are meant to hide behind (the same change made the blocked Cholesky update 1.3 x faster).
         auto fetch = [&](int ks) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int e = t + 256 * i, k = e / TS, r = e % TS;
-                gq[i] = (ks + k < kw && i0 + r < n) ? g[(size_t)(ks + k) * n + i0 + r] : (T)0;
-                bq[i] = (ks + k < kw && j0 + r < ncols) ? bsrc[(size_t)(ks + k) * ldb + j0 + r] : (T)0;
+                const int kc = (ks + k < kw) ? ks + k : kw - 1;
+                gq[i] = g[(size_t)kc * n + ((i0 + r < n) ? i0 + r : n - 1)];
+                bq[i] = bsrc[(size_t)kc * ldb + ((j0 + r < ncols) ? j0 + r : ncols - 1)];
             }
         };
         fetch(0);
@@ -397,9 +405,9 @@ __global__ __launch_bounds__(256) void matinv_bgj_update_mfma(const T *Xold, siz
             __syncthreads();  // the previous slab has been consumed (and rsrc is visible after the first one)
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const int e = t + 256 * i;
-                Gt[e / TS][e % TS] = gq[i];
-                Bt[e / TS][e % TS] = bq[i];
+                const int e = t + 256 * i, k = e / TS, r = e % TS;
+                Gt[k][r] = (ks + k < kw && i0 + r < n) ? gq[i] : (T)0;
+                Bt[k][r] = (ks + k < kw && j0 + r < ncols) ? bq[i] : (T)0;
             }
             __syncthreads();
             if (ks + KS < kw) fetch(ks + KS);
