@@ -232,9 +232,12 @@ def mfma_flops_per_inversion(algo_name, n):
     """fp64 flops the MFMA tile kernels issue per matrix (None for the families without MFMA): a blocked sweep of 4*NT
     rank-4 steps over NT^2 tiles (Gauss-Jordan: all tiles = 2 n^3 flop) or over the NT(NT+1)/2 lower tiles (SPD sweep, one
     wavefront per matrix: n <= 96; the several-wavefront SPD kernels sweep all tiles), 2048 flop per v_mfma_f64_16x16x4_f64.
-    Blocked two-level Gauss-Jordan (n >= 384): 2 n^3."""
+    Blocked two-level Gauss-Jordan (n >= 384): 2 n^3. Blocked SPD inverse (n > 192; update and Y Y^T product on the matrix
+    cores): n^3 -- factor, triangular inverse and product at n^3 / 3 each (the 64 x 64 tile granularity issues more)."""
     if n >= 384 and algo_name == "gj":
         return 2 * n ** 3
+    if n > 192 and algo_name == "chol":
+        return n ** 3
     if n <= 16 or n > 192:
         return None
     nt = (n + 15) // 16
@@ -425,7 +428,7 @@ def main():
         # included -- is driver-timed each round
         del a, x
         for wname in ("gj16", "chol64", "gj32", "gj24", "gj50", "gj8", "gj128", "gj64g", "gj32g", "gj128g", "gj192g", "chol192", "gj256g", "chol256",
-                      "gj1024g"):
+                      "gj1024g", "chol1024"):
             if wname == args.workload:
                 continue
             n2, algo2_name, _ = WORKLOADS[wname]
