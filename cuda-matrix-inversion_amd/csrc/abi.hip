@@ -659,7 +659,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
             if (f64) return "matinv_bgj_update_mfma<double, false, 2>";
             return ((n + 127) / 128) * 128 <= 1.2 * n ? "matinv_bgj_update_mfma<float, false, 4>" : "matinv_bgj_update_mfma<float, false, 2>";
         }
-        return f64 ? "matinv_bgp_panel<double>" : "matinv_bgp_panel<float>";
+        return f64 ? "matinv_bgp_update<double>" : "matinv_bgp_update<float>";  // the trailing update: most of the time
     default: return "";
     }
 }

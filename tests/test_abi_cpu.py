@@ -61,6 +61,12 @@ def test_kernel_selection_is_pure_host_logic():
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 257) == api.KERNEL_BLOCKED
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160) == "matinv_gj_tile4_f64<10, false, 10, false>"
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160, api.KERNEL_TILEP) == "matinv_gj_tilepw_f64<10>"
+    # 16 < n <= 25: the natural-order pass of the tile family is the two-rows-per-lane kernel (csrc/rowlane2_kernels.hip)
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 24) == "matinv_gj_rowlane2<double, 24, true>"
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 20) == "matinv_gj_rowlane2<float, 24, false>"
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 25) == "matinv_gj_rowlane2<double, 32, false>"
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 26) == "matinv_gj_tile_f64<2, false, true>"
+    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 24) == "matinv_spd_tile_f64<2, false>"
     with pytest.raises(pkg("_lib").MatinvError):
         api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 4096)
 
