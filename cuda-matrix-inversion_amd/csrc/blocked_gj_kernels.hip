@@ -20,7 +20,7 @@
 // 3m50s to compile.)
 #include <stdlib.h>
 
-#include "tile_common.hpp"
+#include "slab_mma.hpp"
 
 namespace matinv {
 
@@ -166,14 +166,16 @@ __global__ __launch_bounds__(1024) void matinv_bgj_panel1(const T *Win, T *Wout,
 // x_new[row][col] = (row in K ? 0 : x_old[rowsrc[row]][col]) + sum_k G[row][k] b[k][col]   for the columns outside K
 template <class T>
 __global__ __launch_bounds__(256) void matinv_bgj_update1(const T *Win, T *Wout, const T *Bbuf, const int *rowsrc, int n, int k0,
-                                                         const int *status)
+                                                         const int *status, unsigned g, unsigned nb)
 {
+    const XcdTile tile = xcd_tile_of(blockIdx.x, g, g, nb);  // XCD-aware tile order (slab_mma.hpp)
+    if (!tile.valid) return;
     __shared__ T Gt[BGJ_PB][BGJ_TILE + 1], Bt[BGJ_PB][BGJ_TILE + 1];
     __shared__ int rsrc[BGJ_TILE];
-    const size_t item = blockIdx.z;
+    const size_t item = tile.z;
     if (status[item] != 0) return;
     const int pb = (n - k0 < BGJ_PB) ? n - k0 : BGJ_PB;
-    const int j0 = blockIdx.x * BGJ_TILE, i0 = blockIdx.y * BGJ_TILE;
+    const int j0 = tile.x * BGJ_TILE, i0 = tile.y * BGJ_TILE;
     const T *win = Win + item * (size_t)n * n;
     T *wout = Wout + item * (size_t)n * n;
     const T *b = Bbuf + item * (size_t)BGJ_PB * n;
@@ -357,8 +359,10 @@ template <class T, bool INNER, int MT>
 __global__ __launch_bounds__(256) void matinv_bgj_update_mfma(const T *Xold, size_t old_stride, T *Xnew, size_t new_stride,
                                                               const T *Gsrc, size_t g_stride, const T *Bsrc, size_t b_stride, int ldb,
                                                               const int *rmap, int n, int ncols, int kw, int Z0, int skip0,
-                                                              const int *status)
+                                                              const int *status, unsigned gx, unsigned gy, unsigned nb)
 {
+    const XcdTile tile = xcd_tile_of(blockIdx.x, gx, gy, nb);  // tiles of one tile row share their G slab: one XCD (slab_mma.hpp)
+    if (!tile.valid) return;
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
     constexpr int WT = 16 * MT, TS = 2 * WT;   // wave tile, workgroup tile
@@ -370,9 +374,9 @@ __global__ __launch_bounds__(256) void matinv_bgj_update_mfma(const T *Xold, siz
     constexpr int LDS_ROW = TS + (sizeof(T) == 8 ? 0 : 16);
     __shared__ T Gt[KS][LDS_ROW], Bt[KS][LDS_ROW];
     __shared__ int rsrc[TS];
-    const size_t item = blockIdx.z;
+    const size_t item = tile.z;
     if (status[item] != 0) return;
-    const int j0 = blockIdx.x * TS, i0 = blockIdx.y * TS;  // first column / row of the tile
+    const int j0 = tile.x * TS, i0 = tile.y * TS;  // first column / row of the tile
     const T *xold = Xold + item * old_stride;
     T *xnew = Xnew + item * new_stride;
     const T *g = Gsrc + item * g_stride;
@@ -522,7 +526,7 @@ static hipError_t launch_gj_blocked_small(int n, BatchRef<const T> A, BatchRef<T
         T *cur = W0, *nxt = W1;
         for (int k0 = 0; k0 < n; k0 += BGJ_PB) {
             hipLaunchKernelGGL(matinv_bgj_panel1<T>, dim3(b), dim3(threads), 0, stream, cur, nxt, Bbuf, rowsrc, pivots, n, k0, status);
-            hipLaunchKernelGGL(matinv_bgj_update1<T>, dim3(g, g, b), dim3(256), 0, stream, cur, nxt, Bbuf, rowsrc, n, k0, status);
+            hipLaunchKernelGGL(matinv_bgj_update1<T>, dim3(xcd_tile_grid(g, g, b)), dim3(256), 0, stream, cur, nxt, Bbuf, rowsrc, n, k0, status, g, b);
             T *tmp = cur;
             cur = nxt;
             nxt = tmp;
@@ -581,13 +585,13 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
                                    cnext, pivots, n, bw, c0, K0, status);
                 if (bw > pb) {
                     if (big)
-                        hipLaunchKernelGGL((matinv_bgj_update_mfma<T, true, 4>), dim3((bw + 127) / 128, g128, b), dim3(256), 0, stream, pin,
+                        hipLaunchKernelGGL((matinv_bgj_update_mfma<T, true, 4>), dim3(xcd_tile_grid((bw + 127) / 128, g128, b)), dim3(256), 0, stream, pin,
                                            in_stride, pout, blk, pout + (size_t)c0 * n, blk, Bin, strip, BGJ_NB, rowsrc, n, bw, pb, K0 + c0,
-                                           c0, status);
+                                           c0, status, (unsigned)((bw + 127) / 128), g128, b);
                     else
-                        hipLaunchKernelGGL((matinv_bgj_update_mfma<T, true, 2>), dim3((bw + 63) / 64, g, b), dim3(256), 0, stream, pin,
+                        hipLaunchKernelGGL((matinv_bgj_update_mfma<T, true, 2>), dim3(xcd_tile_grid((bw + 63) / 64, g, b)), dim3(256), 0, stream, pin,
                                            in_stride, pout, blk, pout + (size_t)c0 * n, blk, Bin, strip, BGJ_NB, rowsrc, n, bw, pb, K0 + c0,
-                                           c0, status);
+                                           c0, status, (unsigned)((bw + 63) / 64), g, b);
                 }
                 pin = pout, in_stride = blk;
                 pout = (pout == P0) ? P1 : P0;
@@ -599,11 +603,11 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
                 hipLaunchKernelGGL(matinv_bgj_pivot_rows<T>, dim3((n + 63) / 64, b), dim3(256), 0, stream, cur, Bfull, cprev, n, bw, K0,
                                    status);
             if (big)
-                hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 4>), dim3(g128, g128, b), dim3(256), 0, stream, cur, nn, nxt, nn, pin,
-                                   blk, Bfull, blk, n, cprev, n, n, bw, K0, K0, status);
+                hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 4>), dim3(xcd_tile_grid(g128, g128, b)), dim3(256), 0, stream, cur, nn, nxt, nn, pin,
+                                   blk, Bfull, blk, n, cprev, n, n, bw, K0, K0, status, g128, g128, b);
             else
-                hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 2>), dim3(g, g, b), dim3(256), 0, stream, cur, nn, nxt, nn, pin, blk,
-                                   Bfull, blk, n, cprev, n, n, bw, K0, K0, status);
+                hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 2>), dim3(xcd_tile_grid(g, g, b)), dim3(256), 0, stream, cur, nn, nxt, nn, pin, blk,
+                                   Bfull, blk, n, cprev, n, n, bw, K0, K0, status, g, g, b);
             T *tmp = cur;
             cur = nxt;
             nxt = tmp;

@@ -49,24 +49,6 @@ static bool bgp_pad_on()
 template <class T>
 static int bgp_ld(int rows) { return bgp_pad_on() ? bgp_ld_padded<T>(rows) : rows; }
 
-// XCD-aware tile order for the 64 x 64-tile kernels: workgroup h of a 1-D grid runs on XCD h % 8 (round-robin dispatch), and
-// each XCD has its own L2. Tile h is therefore taken from the h % 8-th EIGHTH of the tile list (x fastest, then y, then item),
-// so that the tiles of one tile row of one matrix -- which share their operand panel -- run on ONE XCD at about the same time
-// and fetch it into that L2 once instead of into all eight.
-struct BgpTile { unsigned x, y, z; bool valid; };
-__device__ __forceinline__ BgpTile bgp_tile_of(unsigned h, unsigned gx, unsigned gy, unsigned b)
-{
-    const unsigned total = gx * gy * b, per = (total + 7) / 8;
-    const unsigned lid = (h % 8) * per + h / 8;
-    BgpTile t;
-    t.valid = h / 8 < per && lid < total;
-    t.x = lid % gx;
-    t.y = (lid / gx) % gy;
-    t.z = lid / (gx * gy);
-    return t;
-}
-static unsigned bgp_tile_grid(unsigned gx, unsigned gy, unsigned b) { return ((gx * gy * b + 7) / 8) * 8; }
-
 // working copy layout per item: (n + 2) rows x n columns, COLUMN-major with leading dimension ld >= n + 2 (bgp_ld):
 // element (r, c) at c*ld + r; rows n and n+1 are the border rows a^T and d^T (d = a for the variance).
 template <class T>
@@ -144,7 +126,7 @@ template <class T>
 __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, int ld, int row_end, int kbeg, int kcnt, int jbeg,
                                                                  int jend, const int *status, unsigned gx, unsigned gy, unsigned nb)
 {
-    const BgpTile tile = bgp_tile_of(blockIdx.x, gx, gy, nb);
+    const XcdTile tile = xcd_tile_of(blockIdx.x, gx, gy, nb);
     if (!tile.valid) return;
     typedef TileGeo<T> G;
     __shared__ T Li[BGP_KS][BGP_LDS], Lj[BGP_KS][BGP_LDS];
@@ -251,7 +233,7 @@ static void bgp_pair(T *W, int n, int ld, int k0, int rows1, int rows2, unsigned
     };
     auto update = [&](int kcnt, int jbeg, int jend, int rows_) {
         const unsigned gx = (unsigned)((jend - jbeg + BGP_TILE - 1) / BGP_TILE), gy = (unsigned)((rows_ - jbeg + BGP_TILE - 1) / BGP_TILE);
-        hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(bgp_tile_grid(gx, gy, b)), dim3(BGP_THREADS), 0, stream, W, n, ld, rows_, k0, kcnt,
+        hipLaunchKernelGGL(matinv_bgp_update<T>, dim3(xcd_tile_grid(gx, gy, b)), dim3(BGP_THREADS), 0, stream, W, n, ld, rows_, k0, kcnt,
                            jbeg, jend, status, gx, gy, b);
     };
     panel(k0, rows1);
@@ -336,7 +318,7 @@ template <class T>
 __global__ __launch_bounds__(BGP_THREADS) void matinv_binv_syrk(const T *W, BatchRef<T> Xout, size_t first, int *info, int n,
                                                                 int ld, const int *status, unsigned g, unsigned nb)
 {
-    const BgpTile tile = bgp_tile_of(blockIdx.x, g, g, nb);
+    const XcdTile tile = xcd_tile_of(blockIdx.x, g, g, nb);
     if (!tile.valid) return;
     typedef TileGeo<T> G;
     __shared__ T Yi[BGP_KS][BGP_LDS], Yj[BGP_KS][BGP_LDS];
@@ -422,7 +404,7 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
             bgp_pair<T>(W, n, ld, k0, n + e1, n + e2, b, status, stream);
         }
         const unsigned g = (unsigned)((n + BGP_TILE - 1) / BGP_TILE);
-        hipLaunchKernelGGL(matinv_binv_syrk<T>, dim3(bgp_tile_grid(g, g, b)), dim3(BGP_THREADS), 0, stream, W, X, first, info, n, ld, status,
+        hipLaunchKernelGGL(matinv_binv_syrk<T>, dim3(xcd_tile_grid(g, g, b)), dim3(BGP_THREADS), 0, stream, W, X, first, info, n, ld, status,
                            g, b);
     }
     e = hipGetLastError();

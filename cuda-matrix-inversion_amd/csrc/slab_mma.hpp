@@ -32,4 +32,22 @@ __device__ __forceinline__ void slab_mma(const T (*Sj)[SLAB_LDS], const T (*Si)[
     }
 }
 
+// XCD-aware tile order for the tile kernels of the blocked paths: workgroup h of a 1-D grid runs on XCD h % 8 (round-robin dispatch), and
+// each XCD has its own L2. Tile h is therefore taken from the h % 8-th EIGHTH of the tile list (x fastest, then y, then item),
+// so that the tiles of one tile row of one matrix -- which share their operand panel -- run on ONE XCD at about the same time
+// and fetch it into that L2 once instead of into all eight.
+struct XcdTile { unsigned x, y, z; bool valid; };
+__device__ __forceinline__ XcdTile xcd_tile_of(unsigned h, unsigned gx, unsigned gy, unsigned b)
+{
+    const unsigned total = gx * gy * b, per = (total + 7) / 8;
+    const unsigned lid = (h % 8) * per + h / 8;
+    XcdTile t;
+    t.valid = h / 8 < per && lid < total;
+    t.x = lid % gx;
+    t.y = (lid / gx) % gy;
+    t.z = lid / (gx * gy);
+    return t;
+}
+inline unsigned xcd_tile_grid(unsigned gx, unsigned gy, unsigned b) { return ((gx * gy * b + 7) / 8) * 8; }
+
 }  // namespace matinv
