@@ -334,11 +334,12 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
     }
 }
 
-// fp64, NT <= 6: three workgroups per CU (168 VGPRs; 6 / 32 registers of the full 80^2 / 96^2 instantiations spill) -- the kernel
-// waits on its per-step critical path most of the time, so the extra workgroup is worth more than the spills cost:
-// general 80^2 9.1e6 -> 1.15e7 inv/s, 96^2 6.6e6 -> 8.0e6. NT = 7, 8 need 228 / 254 registers: two per CU.
+// fp64, NT <= 7: three workgroups per CU (168 VGPRs; 6 / 32 / 58 registers of the full 80^2 / 96^2 / 112^2 instantiations spill)
+// -- the kernel waits on its per-step critical path most of the time, so the extra workgroup is worth more than the spills
+// cost: general 80^2 9.1e6 -> 1.15e7 inv/s, 96^2 6.6e6 -> 8.0e6, 100^2 5.9e6 -> 6.3e6. NT = 8 would spill 95 of its 254
+// registers and loses (128^2: 4.1e6 -> 3.6e6): two per CU.
 template <int NT, bool FULL>
-__global__ __launch_bounds__(256, NT <= 6 ? 3 : 2) void matinv_gj_tilep4_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
+__global__ __launch_bounds__(256, NT <= 7 ? 3 : 2) void matinv_gj_tilep4_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
                                                               unsigned batch, int *bad_count, int *bad_list, const int *in_count,
                                                               const int *in_list, int *hint_out)
 {
