@@ -109,17 +109,19 @@ def cpu_baseline(n, algo_name, target_seconds=9.0):
     def timed(cores):
         probe = sample(max(cores * 16, 256))
         oracle.inverse_batched(probe, n, algo, threads=cores)  # warm-up (thread pool, page faults)
-        t0 = time.perf_counter()
-        oracle.inverse_batched(probe, n, algo, threads=cores)
-        dt = max(time.perf_counter() - t0, 1e-6)
-        rate = (probe.size // (n * n)) / dt
-        # a sample of at most ~1 GB, inverted `passes` times back to back so that the timed CPU work is ~target_seconds
-        k = int(min(max(rate * target_seconds, 1024), 1e9 / (n * n * 8)))
-        passes = max(1, int(round(rate * target_seconds / k)))
+        # calibration over >= 0.3 s (one pass over 256 matrices takes a millisecond and can be off by an order of magnitude)
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.3:
+            oracle.inverse_batched(probe, n, algo, threads=cores)
+            reps += 1
+        rate = reps * (probe.size // (n * n)) / (time.perf_counter() - t0)
+        # a sample of at most ~1 GB and about one second per pass, inverted back to back until ~target_seconds of CPU work
+        k = int(min(max(rate * 1.0, 1024), 1e9 / (n * n * 8)))
         a = sample(k)
-        t0 = time.perf_counter()
-        for _ in range(passes):
+        t0, passes = time.perf_counter(), 0
+        while passes == 0 or time.perf_counter() - t0 < target_seconds:
             oracle.inverse_batched(a, n, algo, threads=cores)
+            passes += 1
         dt = time.perf_counter() - t0
         return k * passes / dt, f"{k} SPD {n}x{n} fp64 matrices x {passes} passes, {dt:.1f} s"
 
