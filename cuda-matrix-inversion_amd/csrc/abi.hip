@@ -428,7 +428,10 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             return MATINV_OK;
         }
     }
-    if (tile4_supports(n) || (n > 128 && n <= (sizeof(T) == 8 ? 192 : 208))) {  // tile4_impl.hpp: gp_tile4_wide_supports
+    // One wavefront per tile column up to n = 176: beyond it the blocked path (matrix-core tile products since late r02) is the
+    // faster one -- fp64 192^2: 1.42e6 items/s here, 1.56e6 blocked; fp32 2.65e6 / 2.92e6; at 160^2 this kernel still leads
+    // (2.2e6 / 1.9e6). (The kernel itself serves n <= 192 / 208: tile4_impl.hpp, gp_tile4_wide_supports.)
+    if (tile4_supports(n) || (n > 128 && n <= 176)) {
         static const bool use_tile4 = []() {
             const char *s = getenv("MATINV_GP_TILE4");  // A/B switch for profiling; default on
             return !(s && *s == '0');
