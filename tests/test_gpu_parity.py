@@ -437,6 +437,42 @@ def test_pipeline_large_n_blocked(n, batch, dtype):
     assert info_m.cpu().tolist() == [0] * (batch - 1) + [n // 2 + 1] == info_v.cpu().tolist()
 
 
+@pytest.mark.parametrize("n,batch,dtype", [(200, 530, "f64"), (257, 340, "f32"), (333, 240, "f64")])
+def test_blocked_cholesky_paths_panel_pairs(n, batch, dtype):
+    """Batches large enough for the blocked Cholesky path to apply its 64-column panels in PAIRS (narrow update, second panel,
+    one rank-128 update: blocked_gp_kernels.hip, bgp_pairs_pay) -- the small batches of the tests above take one update per
+    panel. SPD inverse against the oracle and the fused mean against a float64 solve; ragged n (last panel, last pair and
+    last tile incomplete), a not-positive-definite item in the middle whose neighbours must be untouched."""
+    np_t = np.float64 if dtype == "f64" else np.float32
+    tol = 1e-11 if dtype == "f64" else 5e-5
+    a = spd_batch(n, batch, seed=7000 + n)
+    bad = batch // 2
+    dirty = a.reshape(batch, n, n).copy()
+    dirty[bad, 70, 70] = -1.0  # second panel of the first pair
+    got, info = gpu_inverse(dirty.reshape(-1).astype(np_t), n, CH, api.KERNEL_BLOCKED, want_info=True)
+    assert info[bad] == 71 and np.count_nonzero(info) == 1
+    g = as_mats(got.astype(np.float64), n)
+    assert np.isnan(g[bad]).all()
+    ok = np.arange(batch) != bad
+    A = as_mats(a, n)[ok]                      # symmetric: memory order is irrelevant
+    res = np.abs(np.einsum("bij,bjk->bik", A, g[ok]) - np.eye(n)).max()
+    assert res < tol * n, res
+    assert np.array_equal(g[ok], g[ok].transpose(0, 2, 1))
+    want, _ = oracle.inverse_batched(a.reshape(batch, -1)[:6].reshape(-1), n, oracle.ALGO_CHOLESKY)
+    w6 = as_mats(want, n)
+    assert np.abs(g[:6] - w6).max() < tol * np.abs(w6).max() * 10
+    # fused mean on the same matrices: a^T (B + diag c)^-1 d
+    rng = np.random.default_rng(n)
+    va, vc, vd = (rng.random((batch, n)) for _ in range(3))
+    t = [dev(x.reshape(-1).astype(np_t)) for x in (va, a, vc, vd)]
+    info_m = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    m = api.calcluateMean(n, t[0], t[1], t[2], t[3], info=info_m).cpu().numpy().astype(np.float64)
+    assert not info_m.cpu().numpy().any()
+    M = as_mats(a, n) + np.einsum("bi,ij->bij", vc, np.eye(n))
+    wm = np.einsum("bi,bi->b", va, np.linalg.solve(M, vd[:, :, None])[:, :, 0])
+    assert np.abs(m - wm).max() < (1e-10 if dtype == "f64" else 2e-4) * max(1.0, np.abs(wm).max())
+
+
 def test_randomized_sizes_batches_dtypes():
     """Seeded sweep over odd sizes / batch counts (ragged last wavefront, identity padding, every dispatch boundary):
     n in 1..140, batch in 1..260, both precisions, both algorithms, SPD and general inputs."""
