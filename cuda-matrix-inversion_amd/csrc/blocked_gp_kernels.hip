@@ -219,6 +219,8 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_finish(const T *W, con
 // rank-128 tiles cost 3 %: those keep one update per panel.
 static bool bgp_pairs_pay(int n, unsigned b)
 {
+    static const int mode = [] { const char *s = getenv("MATINV_BGP_PAIRS"); return s ? atoi(s) : -1; }();  // 0 / 1: never / always
+    if (mode == 0 || mode == 1) return mode == 1;
     const size_t nt = (size_t)(n + BGP_TILE - 1) / BGP_TILE;
     return (size_t)b * nt * nt / 2 >= 4096;
 }
