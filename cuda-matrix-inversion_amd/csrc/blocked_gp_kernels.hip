@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_init(const T *As, cons
     const T *B = Bs + item * (size_t)n * n;
     for (size_t e = (size_t)blockIdx.x * BGP_THREADS + threadIdx.x; e < (size_t)ld * n; e += (size_t)gridDim.x * BGP_THREADS) {
         const int c = (int)(e / ld), r = (int)(e - (size_t)c * ld);
-        if (r >= n + 2) continue;  // padding of the leading dimension
+        if (r >= n + 2 || r < c) continue;  // padding of the leading dimension; the strict upper triangle is never read
         T v;
         if (r < n) v = (r >= c) ? B[(size_t)c * n + r] + ((r == c) ? Cs[item * n + c] : (T)0) : (T)0;  // lower triangle only
         else if (r == n) v = As[item * n + c];
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_binv_init(BatchRef<const T
     const T *A = Ain.at(first + item);
     for (size_t e = (size_t)blockIdx.x * BGP_THREADS + threadIdx.x; e < (size_t)ld * n; e += (size_t)gridDim.x * BGP_THREADS) {
         const int c = (int)(e / ld), r = (int)(e - (size_t)c * ld);
-        if (r >= 2 * n) continue;  // padding of the leading dimension
+        if (r >= 2 * n || r < c) continue;  // padding of the leading dimension; the strict upper triangle is never read
         w[e] = (r < n) ? ((r >= c) ? A[(size_t)c * n + r] : (T)0) : ((r - n == c) ? (T)1 : (T)0);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) status[item] = 0;
