@@ -96,7 +96,10 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_panel(T *W, int n, int
     if (t < BGP_PB) rinv[t] = (T)1 / L11[t * LD + t];
     __syncthreads();
     // one row per thread: x L11^T = row, right-looking (once x[c] is final it is eliminated from the later entries, so
-    // the dependent chain is PB long and the inner updates are independent FMAs)
+    // the dependent chain is PB long and the inner updates are independent FMAs).
+    // (Tried and measured, not kept: TWO rows per thread in fp32, sharing every L11 entry read from LDS and halving the
+    // workgroups that repeat the factorisation: 170 VGPRs, two waves per SIMD -- fused pipeline 256^2 1.63 -> 2.72 ms,
+    // 1024^2 3.10 -> 3.44 ms, the 8-item bin of the mixed queue 1.05 -> 1.47 ms.)
     const int r = k0 + pb + blockIdx.x * BGP_THREADS + t;
     if (r >= row_end) return;  // rows beyond row_end are still zero in these columns (identity border of the inversion)
     T x[BGP_PB];
