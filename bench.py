@@ -137,7 +137,7 @@ def cpu_baseline(n, algo_name, target_seconds=9.0):
     return out
 
 
-def run_mixed(args, api, device, rank, world):
+def mixed_result(args, api, device, rank, world):
     """BASELINE configs[4]: mixed-size fp32 items n in {32,128,512,1024} through the size-binned multi-queue, full
     add -> inv -> gemv -> dot mean pipeline (fused). Stated mix (items per step and GPU): 32: 16384, 128: 2048, 512: 32,
     1024: 8 -- roughly equal flops per bin is NOT attempted; per-bin rates are reported. One step = submit + flush."""
@@ -216,18 +216,27 @@ def run_mixed(args, api, device, rank, world):
         per_bin[str(n)] = {"items": cnt, "kernel_ms": ms_, "items_per_s": cnt / (ms_ * 1e-3),
                            "roofline": {"bound": "hbm", "achieved": alg / (ms_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": alg / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg}}
+    # the flushed means against the per-bin launches of the same items (the queue adds gather / scatter only)
+    means = step()
+    torch.cuda.synchronize()
+    total = sum(mix.values()) * world * args.steps
+    return {
+        "metric": "pipeline items/s (mixed sizes)", "value": total / elapsed, "unit": "items/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "mixed: fp32 mean pipeline, size-binned queues 32/128/512/1024 (BASELINE configs[4])",
+                   "mix_items_per_step_per_gpu": mix, "queue": "C (matinv_queue_*, csrc/queue.hip)",
+                   "includes": "submit of same-size chunks of <= 256 items (sizes interleaved) + flush: segmented gather + one fused launch per size, one stream per bin"},
+        "host_ms_per_step": host_idle_ms, "host_share": host_idle_ms / (elapsed / args.steps * 1e3),
+        "host_ms_in_calls_back_to_back": host_s[0] / args.steps * 1e3,
+        "means_finite": bool(torch.isfinite(means).all()),
+        "per_bin": per_bin}
+
+
+def run_mixed(args, api, device, rank, world):
+    out = mixed_result(args, api, device, rank, world)
     if rank == 0:
-        total = sum(mix.values()) * world * args.steps
-        print(json.dumps({
-            "metric": "pipeline items/s (mixed sizes)", "value": total / elapsed, "unit": "items/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "mixed: fp32 mean pipeline, size-binned queues 32/128/512/1024 (BASELINE configs[4])",
-                       "mix_items_per_step_per_gpu": mix, "queue": "C (matinv_queue_*, csrc/queue.hip)",
-                       "includes": "submit of same-size chunks of <= 256 items (sizes interleaved) + flush: segmented gather + one fused launch per size, one stream per bin"},
-            "host_ms_per_step": host_idle_ms, "host_share": host_idle_ms / (elapsed / args.steps * 1e3),
-            "host_ms_in_calls_back_to_back": host_s[0] / args.steps * 1e3,
-            "per_bin": per_bin}), flush=True)
+        print(json.dumps(out), flush=True)
 
 
 def mfma_flops_per_inversion(algo_name, n):
@@ -236,7 +245,9 @@ def mfma_flops_per_inversion(algo_name, n):
     wavefront per matrix: n <= 96; the several-wavefront SPD kernels sweep all tiles), 2048 flop per v_mfma_f64_16x16x4_f64.
     Blocked two-level Gauss-Jordan (n >= 384): 2 n^3. Blocked SPD inverse (n > 192; update and Y Y^T product on the matrix
     cores): n^3 -- factor, triangular inverse and product at n^3 / 3 each (the 64 x 64 tile granularity issues more)."""
-    if n >= 384 and algo_name == "gj":
+    if n > 192 and algo_name == "gj":
+        # blocked Gauss-Jordan: 2 n^3 algorithmic flops. n >= 384: rank-128 update on the matrix cores; 192 < n < 384: rank-32
+        # update on the vector ALU, priced against the fp64 VECTOR peak, which on gfx950 equals the matrix peak (same datapath)
         return 2 * n ** 3
     if n > 192 and algo_name == "chol":
         return n ** 3
@@ -244,7 +255,9 @@ def mfma_flops_per_inversion(algo_name, n):
         return None
     nt = (n + 15) // 16
     tiles = nt * nt if (algo_name == "gj" or n > 96) else nt * (nt + 1) // 2
-    return 4 * nt * tiles * 2048
+    # block steps actually executed: the all-padding 4-column blocks of the last tile column are skipped (fp64: ceil(rem / 4))
+    steps = 4 * (nt - 1) + (n - 16 * (nt - 1) + 3) // 4
+    return steps * tiles * 2048
 
 
 def rooflines(algo_name, n, batch, kern_ms):
@@ -260,6 +273,8 @@ def rooflines(algo_name, n, batch, kern_ms):
     tf = batch * fl / (kern_ms * 1e-3) / 1e12
     mf = {"bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
           "algorithmic_flops_per_launch": batch * fl}
+    if algo_name == "gj" and 192 < n < 384:
+        mf["pipe"] = "fp64 vector ALU (same peak as the matrix cores on gfx950)"
     return (hbm, mf) if hbm["frac"] >= mf["frac"] else (mf, hbm)
 
 
@@ -319,9 +334,14 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # MATINV_BENCH_FORCE_DIST=1: a process group even for one rank (a world-size-1 "nccl" group is how the RCCL branch of this
+    # file is exercised on a one-GPU box: tests/test_gpu_multirank.py)
+    if world > 1 or os.environ.get("MATINV_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -354,6 +374,8 @@ def main():
                     f"no data-path collective")
 
     general = args.workload in GENERAL
+    if general and kernel == api.KERNEL_AUTO and 16 < n <= 192:
+        kernel = api.KERNEL_TILEP  # general input: the caller asks for partial pivoting (see other_workloads)
     a = (make_general if general else make_spd)(n, batch, 0x5EED + rank, device)
     x = torch.empty_like(a)
     info = torch.empty(max(batch, 1), dtype=torch.int32, device=device)
@@ -400,11 +422,14 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             g0 = time.perf_counter()
-            # result reassembly on every rank (ONE RCCL all-gather over xGMI); host staging only in the gloo rehearsal
-            full = shard.all_gather_shards(x if backend == "nccl" else x.cpu(), n, total_batch)
+            # result reassembly on every rank (ONE RCCL all-gather over xGMI); host staging only in the gloo rehearsal.
+            # MATINV_GATHER=c: through the C ABI (matinv_allgather_shards on the library's own RCCL communicator)
+            gimpl = os.environ.get("MATINV_GATHER", "torch") if backend == "nccl" else "torch"
+            full = shard.all_gather_shards(x if backend == "nccl" else x.cpu(), n, total_batch, impl=gimpl)
             torch.cuda.synchronize()
             gms = (time.perf_counter() - g0) * 1e3
             assert full.numel() == total_batch * n * n
+            mine_ok = bool(torch.equal(full[lo * n * n:(lo + batch) * n * n].to(x.device), x))
             recv = (total_batch - batch) * n * n * x.element_size()  # bytes this rank received from the others
             tg = torch.tensor([gms], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tg, op=dist.ReduceOp.MAX)
@@ -412,7 +437,8 @@ def main():
             gather = {"allgather_ms": gms, "allgather_GBs_per_rank_in": recv / (gms * 1e-3) / 1e9,
                       "gathered_bytes_per_rank": total_batch * n * n * x.element_size(),
                       "xgmi_bound_GBs_per_rank_in": XGMI_LINK_GBS * min(world - 1, 7),
-                      "xgmi_per_link_GBs": XGMI_LINK_GBS, "backend": backend}
+                      "xgmi_per_link_GBs": XGMI_LINK_GBS, "backend": backend, "impl": gimpl,
+                      "gather_equals_local_result": mine_ok}
             del full
         else:
             gather = {"backend": backend}
@@ -422,41 +448,95 @@ def main():
     am = a.view(batch, n, n)[:8]
     xm = x.view(batch, n, n)[:8]
     resid = float((torch.bmm(am, xm) - torch.eye(n, dtype=a.dtype, device=device)).abs().max())
-    assert resid < (1e-9 if general else 1e-11) * n, f"residual {resid}"
+    if os.environ.get("MATINV_BENCH_NO_RESIDUAL") != "1":  # (profiling builds that move the bytes without inverting)
+        assert resid < (1e-9 if general else 1e-11) * n, f"residual {resid}"
 
-    others = {}
+    others, end_to_end, mixed = {}, None, None
     if rank == 0 and world == 1 and not args.no_others:
         # the other single-GPU workloads, a few launches each (same timing method), so that every path -- the weak ones
-        # included -- is driver-timed each round
+        # included -- is driver-timed AND residual-checked each round
         del a, x
+
+        def residual(a_, x_, n_, b_, k=64):
+            """max_k || A_k X_k - I ||_inf-entry over k matrices spread through the batch (first, last and evenly between);
+            the flat batches are column-major, i.e. the views are A^T and X^T: (A^T)(X^T) = (X A)^T -- the left residual"""
+            idx = torch.linspace(0, b_ - 1, min(k, b_), device=device).long()
+            am_ = a_.view(b_, n_, n_)[idx]
+            xm_ = x_.view(b_, n_, n_)[idx]
+            return float((torch.bmm(am_, xm_) - torch.eye(n_, dtype=a_.dtype, device=device)).abs().max())
+
+        def one(wname, b2, reps=5, natural_first=False):
+            n2, algo2_name, _ = WORKLOADS[wname]
+            algo2 = api.ALGO_GAUSS_JORDAN if algo2_name == "gj" else api.ALGO_CHOLESKY
+            gen2 = wname in GENERAL
+            a2 = (make_general if gen2 else make_spd)(n2, b2, 0x5EED + 17 * n2, device)
+            x2 = torch.empty_like(a2)
+            i2 = torch.empty(b2, dtype=torch.int32, device=device)
+            # general input: the caller asks for partial pivoting (MATINV_KERNEL_TILEP; what the reference's inverse_lu_cuda_batched_*
+            # names map to) -- the default Gauss-Jordan policy tries the natural order first, per matrix (deterministic), and a
+            # general batch would pay both kernels: that figure is the "@natural_first" entry below
+            k2 = api.KERNEL_TILEP if (gen2 and 16 < n2 <= 192 and not natural_first) else api.KERNEL_AUTO
+            for _ in range(3):
+                api.inverse_batched(a2, n2, algo2, out=x2, info=i2, batch=b2, kernel=k2)
+            ms2 = float(np.mean(time_launches(lambda: api.inverse_batched(a2, n2, algo2, out=x2, batch=b2, kernel=k2), reps)))
+            r1, r2 = rooflines(algo2_name, n2, b2, ms2)
+            kname2 = api.kernel_name(algo2, api.F64, n2, k2)
+            res2 = residual(a2, x2, n2, b2)
+            # general U(0,1) matrices have condition numbers of 1e3 .. 1e6 at these sizes: the residual bound scales with it
+            tol2 = (1e-7 if gen2 else 1e-11) * n2
+            assert res2 < tol2, f"{wname}: residual {res2} >= {tol2}"
+            d = {"kernel": kname2, "batch": b2, "kernel_ms": ms2, "input": "general U(0,1)" if gen2 else "SPD",
+                 "inversions_per_s": b2 / (ms2 * 1e-3), "bound": r1["bound"], "frac": r1["frac"],
+                 "achieved": r1["achieved"], "unit": r1["unit"],
+                 "other_bound_frac": None if r2 is None else r2["frac"], "singular_reported": int((i2 != 0).sum()),
+                 "residual_max_64": res2, "residual_tol": tol2}
+            del a2, x2
+            return d
+
         for wname in ("gj16", "chol64", "gj32", "gj24", "gj50", "gj8", "gj128", "gj64g", "gj32g", "gj128g", "gj192g", "chol192", "gj256g", "chol256",
                       "gj1024g", "chol1024"):
             if wname == args.workload:
                 continue
-            n2, algo2_name, _ = WORKLOADS[wname]
-            algo2 = api.ALGO_GAUSS_JORDAN if algo2_name == "gj" else api.ALGO_CHOLESKY
-            b2 = 100_000 if n2 <= 64 else (25_000 if n2 <= 128 else (5_000 if n2 <= 192 else (3_000 if n2 <= 256 else 256)))
-            a2 = (make_general if wname in GENERAL else make_spd)(n2, b2, 0x5EED + 17 * n2, device)
-            x2 = torch.empty_like(a2)
-            i2 = torch.empty(b2, dtype=torch.int32, device=device)
-            for _ in range(3):  # the adaptive dispatch of the tile family settles on the second launch
-                api.inverse_batched(a2, n2, algo2, out=x2, info=i2, batch=b2)
-            ms2 = float(np.mean(time_launches(lambda: api.inverse_batched(a2, n2, algo2, out=x2, batch=b2), 5)))
-            r1, r2 = rooflines(algo2_name, n2, b2, ms2)
-            kname2 = api.kernel_name(algo2, api.F64, n2)
-            if wname in GENERAL and 16 < n2 <= 192:
-                kname2 = api.kernel_name(algo2, api.F64, n2, api.KERNEL_TILEP)  # where the adaptive dispatch sends a general batch
-            others[wname] = {"kernel": kname2, "batch": b2, "kernel_ms": ms2, "input": "general U(0,1)" if wname in GENERAL else "SPD",
-                             "inversions_per_s": b2 / (ms2 * 1e-3), "bound": r1["bound"], "frac": r1["frac"],
-                             "achieved": r1["achieved"], "unit": r1["unit"],
-                             "other_bound_frac": None if r2 is None else r2["frac"], "singular_reported": int((i2 != 0).sum())}
-            del a2, x2
+            n2 = WORKLOADS[wname][0]
+            others[wname] = one(wname, 100_000 if n2 <= 64 else (25_000 if n2 <= 128 else (5_000 if n2 <= 192 else (3_000 if n2 <= 256 else 256))))
+        # the small sizes again at a batch whose working set is beyond the 256 MiB Infinity Cache (100 k x 16^2 x 2 = 0.4 GB is
+        # not: FETCH_SIZE counts those hits, so the 100 k figure may flatter them)
+        for wname, b2 in (("gj16", 1_000_000), ("gj8", 2_000_000)):
+            others[wname + f"@{b2 // 1_000_000}M"] = one(wname, b2)
+        # what a GENERAL batch costs under the default (per-matrix deterministic) policy: natural-order attempt + pivoting kernel
+        others["gj64g@natural_first"] = one("gj64g", 100_000, natural_first=True)
+
+        # End to end, as the reference times it (src/inverse_bench.c:187-200: TIMER around the host-pointer call; H2D + kernel + D2H
+        # inside, caller's pageable memory in and out). Never `value`.
+        n_e, b_e = 64, 100_000
+        rng = np.random.default_rng(1)
+        r_ = rng.random((2_000, n_e, n_e))
+        ha = np.tile((r_ + r_.transpose(0, 2, 1) + n_e * np.eye(n_e)).reshape(-1), b_e // 2_000)
+        hx = np.empty_like(ha)
+        api.inverse_gauss_batched_gpu(n_e, ha, hx, b_e)  # warm-up: staging pool, page faults of the output
+        ts = []
+        for _ in range(3):
+            t_ = time.perf_counter()
+            api.inverse_gauss_batched_gpu(n_e, ha, hx, b_e)
+            ts.append(time.perf_counter() - t_)
+        t_e = float(np.median(ts))
+        k_ = b_e - 1
+        he = np.abs(ha[k_ * n_e * n_e:].reshape(n_e, n_e) @ hx[k_ * n_e * n_e:].reshape(n_e, n_e) - np.eye(n_e)).max()
+        assert he < 1e-11 * n_e, f"end-to-end residual {he}"
+        end_to_end = {"call": "inverse_gauss_batched_gpu(handle, 64, As, aInvs, 100000): host pointers, pageable memory, H2D + kernel + D2H inside (src/inverse_bench.c:187-200)",
+                      "ms": t_e * 1e3, "inversions_per_s": b_e / t_e, "host_link_GBs_both_directions": 2 * ha.nbytes / t_e / 1e9,
+                      "host_link_spec_GBs_per_direction": 63.0, "devices": int(os.environ.get("MATINV_DEVICES", "1")),
+                      "residual_last_matrix": float(he), "calls_timed": len(ts)}
+        del ha, hx
+
+        # BASELINE configs[4] on this GPU (the C queue), a short run of the same code path as --workload mixed
+        margs = argparse.Namespace(steps=10, warmup=3)
+        mixed = mixed_result(margs, api, device, rank, world)
+        mixed = {k: mixed[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "host_ms_per_step", "host_share", "means_finite", "per_bin", "config")}
 
     if rank == 0:
         value = total_batch * args.steps / elapsed
         kname = api.kernel_name(algo, api.F64, n, kernel)
-        if general and 16 < n <= 192 and kernel == api.KERNEL_AUTO:
-            kname = api.kernel_name(algo, api.F64, n, api.KERNEL_TILEP)  # where the adaptive dispatch sends a general batch
         roof, roof_other = rooflines(algo_name, n, batch, kern_ms)
         traffic, traffic_src = load_traffic(kname, n, batch)
         roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "kernel_ms": kern_ms,
@@ -483,6 +563,10 @@ def main():
                 out["allgather_ms"] = gather["allgather_ms"]
         if others:
             out["other_workloads"] = others
+        if end_to_end is not None:
+            out["end_to_end"] = end_to_end
+        if mixed is not None:
+            out["mixed"] = mixed
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, algo_name)
         print(json.dumps(out), flush=True)

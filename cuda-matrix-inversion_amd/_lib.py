@@ -36,7 +36,10 @@ NATIVE_NAMES = [
     "matinv_abi_version", "matinv_release_cache", "matinv_batched_malloc", "matinv_batched_free", "matinv_memcpy_2d",
     "matinv_device_synchronize", "matinv_tile_stats", "matinv_queue_create", "matinv_queue_submit", "matinv_queue_submit_chunks", "matinv_queue_pending",
     "matinv_queue_bins", "matinv_queue_flush", "matinv_queue_destroy", "matinv_queue_last_error",
+    "matinv_set_gj_policy", "matinv_device_count", "matinv_inverse_batched_host_multi", "matinv_comm_unique_id",
+    "matinv_comm_init_rank", "matinv_comm_destroy", "matinv_allgather_shards", "matinv_allgather_local",
 ]
+GJ_NATURAL_FIRST, GJ_PIVOT, GJ_ADAPTIVE = 0, 1, 2
 
 
 def build(force: bool = False) -> str:
@@ -82,6 +85,21 @@ def lib() -> ctypes.CDLL:
     for f in (L.matinv_mean_batched_host, L.matinv_variance_batched_host):
         f.restype = ci
         f.argtypes = [ci, ci, vp, vp, vp, vp, vp, sz, vp]
+    L.matinv_inverse_batched_host_multi.restype = ci
+    L.matinv_inverse_batched_host_multi.argtypes = [ci, ci, ci, vp, vp, sz, vp, ci]
+    L.matinv_set_gj_policy.restype = ci
+    L.matinv_set_gj_policy.argtypes = [ci]
+    L.matinv_device_count.restype = ci
+    L.matinv_comm_unique_id.restype = ci
+    L.matinv_comm_unique_id.argtypes = [vp]
+    L.matinv_comm_init_rank.restype = ci
+    L.matinv_comm_init_rank.argtypes = [vp, ci, vp, ci]
+    L.matinv_comm_destroy.restype = ci
+    L.matinv_comm_destroy.argtypes = [vp]
+    L.matinv_allgather_shards.restype = ci
+    L.matinv_allgather_shards.argtypes = [vp, ci, vp, vp, sz, vp]
+    L.matinv_allgather_local.restype = ci
+    L.matinv_allgather_local.argtypes = [ci, vp, ci, vp, vp, sz]
     L.matinv_tile_stats.restype = ci
     L.matinv_tile_stats.argtypes = [vp, vp, vp, vp]
     L.matinv_batched_malloc.restype = ci

@@ -19,7 +19,8 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (ALGO_CHOLESKY, ALGO_GAUSS_JORDAN, F32, F64, KERNEL_AUTO, KERNEL_BLOCKED, KERNEL_GLOBAL, KERNEL_LDS,  # noqa: F401
+from ._lib import (GJ_ADAPTIVE, GJ_NATURAL_FIRST, GJ_PIVOT,  # noqa: F401
+                   ALGO_CHOLESKY, ALGO_GAUSS_JORDAN, F32, F64, KERNEL_AUTO, KERNEL_BLOCKED, KERNEL_GLOBAL, KERNEL_LDS,  # noqa: F401
                    KERNEL_ROW, KERNEL_ROWLANE, KERNEL_TILE, KERNEL_TILEP, MatinvError)
 
 
@@ -91,6 +92,34 @@ def inverse_batched_host(As: np.ndarray, n: int, algo: int = ALGO_GAUSS_JORDAN):
         algo, _np_dtype_code(As.dtype), n, As.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
         batch, info.ctypes.data_as(ctypes.c_void_p)))
     return out, info
+
+
+def inverse_batched_host_multi(As: np.ndarray, n: int, algo: int = ALGO_GAUSS_JORDAN, nshards: int = 0):
+    """matinv_inverse_batched_host_multi: the batch block-partitioned over `nshards` shards (0 = one per visible device),
+    one host thread and one device per shard, results back in host memory; no collective. Returns (aInvs, info)."""
+    As = np.ascontiguousarray(As)
+    batch = As.size // (n * n)
+    out = np.empty_like(As)
+    info = np.zeros(batch, dtype=np.int32)
+    _lib.check(_lib.lib().matinv_inverse_batched_host_multi(
+        algo, _np_dtype_code(As.dtype), n, As.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+        batch, info.ctypes.data_as(ctypes.c_void_p), int(nshards)))
+    return out, info
+
+
+def device_count() -> int:
+    k = _lib.lib().matinv_device_count()
+    if k < 0:
+        _lib.check(k)
+    return k
+
+
+def set_gj_policy(policy: int) -> int:
+    """matinv_set_gj_policy (GJ_NATURAL_FIRST / GJ_PIVOT / GJ_ADAPTIVE); returns the previous policy."""
+    old = _lib.lib().matinv_set_gj_policy(int(policy))
+    if old < 0:
+        _lib.check(old)
+    return old
 
 
 # -------------------------------------------------------------------------------------------- device family

@@ -152,7 +152,9 @@ class SizeBinnedQueue:
 
     def flush(self) -> Tuple["torch.Tensor", Optional["torch.Tensor"]]:
         """Run every bin; returns (means, variances or None) in ticket order and empties the queue. Variances are computed
-        when every pending item carried an e. Asynchronous on torch's current stream."""
+        only when EVERY pending item carried an e (a submission that mixes items with and without e gets means only).
+        Asynchronous on torch's current stream. The queue is empty afterwards whether the flush succeeded or raised -- the
+        C queue clears itself in both cases, and this mirror follows it."""
         import torch
         total = self._tickets
         if total == 0:
@@ -160,18 +162,20 @@ class SizeBinnedQueue:
         means = torch.empty(total, dtype=self._dtype, device=self.device)
         variances = torch.empty(total, dtype=self._dtype, device=self.device) if self._want_var else None
         stream = torch.cuda.current_stream(self.device)
-        with torch.cuda.device(self.device):
-            rc = _lib.lib().matinv_queue_flush(self._q, ctypes.c_void_p(means.data_ptr()),
-                                               ctypes.c_void_p(variances.data_ptr()) if variances is not None else None,
-                                               ctypes.c_void_p(stream.cuda_stream))
-        if rc != _lib.OK:
-            raise _lib.MatinvError(rc, _lib.lib().matinv_queue_last_error(self._q).decode())
-        # the chunks must outlive the asynchronous launches: their memory is returned to torch's caching allocator only
-        # after the current stream has passed this point
-        for ts in self._keep:
-            for t in ts:
-                t.record_stream(stream)
-        self._keep = []
-        self._tickets = 0
-        self._want_var = True
+        try:
+            with torch.cuda.device(self.device):
+                rc = _lib.lib().matinv_queue_flush(self._q, ctypes.c_void_p(means.data_ptr()),
+                                                   ctypes.c_void_p(variances.data_ptr()) if variances is not None else None,
+                                                   ctypes.c_void_p(stream.cuda_stream))
+            if rc != _lib.OK:
+                raise _lib.MatinvError(rc, _lib.lib().matinv_queue_last_error(self._q).decode())
+        finally:
+            # the chunks must outlive the asynchronous launches (also those of a flush that failed half way): their memory is
+            # returned to torch's caching allocator only after the current stream has passed this point
+            for ts in self._keep:
+                for t in ts:
+                    t.record_stream(stream)
+            self._keep = []
+            self._tickets = 0
+            self._want_var = True
         return means, variances

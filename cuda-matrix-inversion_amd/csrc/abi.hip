@@ -9,6 +9,9 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/matinv.h"
@@ -17,9 +20,10 @@
 using namespace matinv;
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
+namespace matinv {
 int fail(int code, const char *fmt, ...)
 {
     va_list ap;
@@ -33,6 +37,9 @@ int fail_hip(hipError_t e, const char *what)
 {
     return fail(MATINV_ERR_HIP, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
 }
+}  // namespace matinv
+
+namespace {
 
 // The library is built for gfx950 only; refuse anything else instead of faulting in the launch.
 int check_device()
@@ -49,33 +56,16 @@ int check_device()
         return fail(MATINV_ERR_NO_DEVICE, "device %d is %s; libmatinv_hip is built for gfx950 (MI355X) only", dev,
                     prop.gcnArchName);
     checked_dev = dev;
-    // Work lists and the workspaces of the blocked paths are stream-ordered allocations (hipMallocAsync) that are freed again
-    // inside the call: keep what is freed in the device's pool instead of handing it back to the driver at the next
-    // synchronisation (the default release threshold is 0 -- a 5 GB workspace then costs ~20 ms to get back on every call).
-    hipMemPool_t pool;
-    unsigned long long keep = ~0ull;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     return MATINV_OK;
 }
 
-// Staging buffers of the host-pointer entry points come from the device's default memory pool with its release threshold
-// raised once, so that the reference-style "allocate, copy, run, copy, free inside every call" (batched_invert.cu:120-176)
-// stops paying hipMalloc / hipFree (about 0.5 ms per call) after the first call; the pool hands the same blocks back.
-hipError_t staging_alloc(void **p, size_t bytes)
-{
-    static const bool pool_ready = []() {
-        int dev = 0;
-        hipMemPool_t pool;
-        unsigned long long keep = ~0ull;
-        return hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess &&
-               hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess;
-    }();
-    (void)pool_ready;
-    return hipMallocAsync(p, bytes, nullptr);
-}
+// Staging buffers of the host-pointer entry points: the library's scratch cache (scratch.hip), so that the reference-style
+// "allocate, copy, run, copy, free inside every call" (batched_invert.cu:120-176) stops paying hipMalloc / hipFree (about 0.5 ms
+// per call) after the first call.
+hipError_t staging_alloc(void **p, size_t bytes) { return scratch_alloc(p, bytes, nullptr); }
 void staging_free(void *p)
 {
-    if (p) (void)hipFreeAsync(p, nullptr);
+    if (p) (void)scratch_free(p, nullptr);
 }
 
 template <class T>
@@ -219,7 +209,8 @@ void timer_log(const char *prefix, const char *phase, size_t batch, int n, doubl
 // Returns MATINV_ERR_UNSUPPORTED (without touching the output) when the buffers cannot be registered; the caller then
 // takes the simple path.
 template <class T>
-int inverse_host_pipelined(int algo, int n, const T *hA, T *hAinv, size_t batch, int *info, int kernel, double &ms_total)
+int inverse_host_pipelined(int algo, int n, const T *hA, T *hAinv, size_t batch, int *info, int kernel, double &ms_total,
+                           bool registered = false)
 {
     constexpr int NS = 3;  // streams / chunk slots in flight
     const size_t mat = (size_t)n * n, bytes_mat = mat * sizeof(T);
@@ -227,14 +218,16 @@ int inverse_host_pipelined(int algo, int n, const T *hA, T *hAinv, size_t batch,
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
     const double t0 = now_ms();
-    if (hipHostRegister(const_cast<T *>(hA), batch * bytes_mat, hipHostRegisterDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        return MATINV_ERR_UNSUPPORTED;
-    }
-    if (hipHostRegister(hAinv, batch * bytes_mat, hipHostRegisterDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipHostUnregister(const_cast<T *>(hA));
-        return MATINV_ERR_UNSUPPORTED;
+    if (!registered) {
+        if (hipHostRegister(const_cast<T *>(hA), batch * bytes_mat, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return MATINV_ERR_UNSUPPORTED;
+        }
+        if (hipHostRegister(hAinv, batch * bytes_mat, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostUnregister(const_cast<T *>(hA));
+            return MATINV_ERR_UNSUPPORTED;
+        }
     }
     hipStream_t st[NS] = {};
     T *dA[NS] = {}, *dX[NS] = {};
@@ -243,9 +236,9 @@ int inverse_host_pipelined(int algo, int n, const T *hA, T *hAinv, size_t batch,
     int rc = MATINV_OK;
     for (int s = 0; s < NS && e == hipSuccess; ++s) {
         e = hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMalloc(&dA[s], chunk * bytes_mat);
-        if (e == hipSuccess) e = hipMalloc(&dX[s], chunk * bytes_mat);
-        if (e == hipSuccess && info) e = hipMalloc(&dI[s], chunk * sizeof(int));
+        if (e == hipSuccess) e = scratch_alloc(reinterpret_cast<void **>(&dA[s]), chunk * bytes_mat, st[s]);
+        if (e == hipSuccess) e = scratch_alloc(reinterpret_cast<void **>(&dX[s]), chunk * bytes_mat, st[s]);
+        if (e == hipSuccess && info) e = scratch_alloc(reinterpret_cast<void **>(&dI[s]), chunk * sizeof(int), st[s]);
     }
     size_t slot = 0;
     for (size_t off = 0; off < batch && e == hipSuccess && rc == MATINV_OK; off += chunk, ++slot) {
@@ -264,14 +257,19 @@ int inverse_host_pipelined(int algo, int n, const T *hA, T *hAinv, size_t batch,
         if (st[s]) {
             hipError_t es = hipStreamSynchronize(st[s]);
             if (e == hipSuccess) e = es;
+        }
+        if (dA[s]) (void)scratch_free(dA[s], st[s]);
+        if (dX[s]) (void)scratch_free(dX[s], st[s]);
+        if (dI[s]) (void)scratch_free(dI[s], st[s]);
+        if (st[s]) {
+            scratch_retire_stream(st[s]);  // synchronised above: its blocks may serve any stream of this device from now on
             (void)hipStreamDestroy(st[s]);
         }
-        if (dA[s]) (void)hipFree(dA[s]);
-        if (dX[s]) (void)hipFree(dX[s]);
-        if (dI[s]) (void)hipFree(dI[s]);
     }
-    (void)hipHostUnregister(const_cast<T *>(hA));
-    (void)hipHostUnregister(hAinv);
+    if (!registered) {
+        (void)hipHostUnregister(const_cast<T *>(hA));
+        (void)hipHostUnregister(hAinv);
+    }
     ms_total = now_ms() - t0;
     if (rc != MATINV_OK) return rc;
     if (e != hipSuccess) return fail_hip(e, "pipelined host<->device transfer");
@@ -279,12 +277,27 @@ int inverse_host_pipelined(int algo, int n, const T *hA, T *hAinv, size_t batch,
 }
 
 template <class T>
+int inverse_host_multi(int algo, int n, const void *hA, void *hAinv, size_t batch, int *info, int nshards, int kernel);
+
+// MATINV_DEVICES=N (> 1): the host-pointer entry points shard over N devices (matinv_inverse_batched_host_multi)
+int env_devices()
+{
+    static const int v = []() {
+        const char *s = getenv("MATINV_DEVICES");
+        return s && *s ? atoi(s) : 0;
+    }();
+    return v;
+}
+
+// `registered`: the caller (the multi-device driver) has page-locked both host buffers for every device already
+template <class T>
 int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int *info, const char *log_prefix,
-                 int kernel = MATINV_KERNEL_AUTO)
+                 int kernel = MATINV_KERNEL_AUTO, bool single_device = false, bool registered = false)
 {
     if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
     if (batch == 0) return MATINV_OK;
     if (!hA || !hAinv) return fail(MATINV_ERR_ARG, "null host pointer");
+    if (!single_device && env_devices() > 1) return inverse_host_multi<T>(algo, n, hA, hAinv, batch, info, env_devices(), kernel);
     int rc = check_device();
     if (rc) return rc;
     const size_t elems = (size_t)n * n * batch;  // size_t: 1M x 64 x 64 overflows the reference's int index
@@ -295,10 +308,10 @@ int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int
             return s && *s ? atoi(s) : -1;
         }();
         const bool big = elems * sizeof(T) >= ((size_t)128 << 20);
-        if (hA != hAinv && (mode == 1 || (mode < 0 && big))) {
+        if (hA != hAinv && (registered || mode == 1 || (mode < 0 && big))) {
             double ms = 0;
             const int prc = inverse_host_pipelined<T>(algo, n, static_cast<const T *>(hA), static_cast<T *>(hAinv), batch, info,
-                                                      kernel, ms);
+                                                      kernel, ms, registered);
             if (prc != MATINV_ERR_UNSUPPORTED) {
                 if (prc == MATINV_OK && detailed_logging() && log_prefix) timer_log(log_prefix, "pipelined_total", batch, n, ms);
                 return prc;
@@ -344,11 +357,88 @@ int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int
     return MATINV_OK;
 }
 
+int gfx950_devices(std::vector<int> &devs)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return fail(MATINV_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    for (int d = 0; d < count; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) devs.push_back(d);
+    }
+    if (devs.empty()) return fail(MATINV_ERR_NO_DEVICE, "no gfx950 (MI355X) device visible");
+    return MATINV_OK;
+}
+
+// The batch over several devices of this process: contiguous blocks (the partition of shard.py / SURVEY 8e: ceil(batch /
+// nshards) rounded up to the per-wavefront packing factor), one host thread per shard with hipSetDevice, each running the
+// single-device host path on its slice -- the pipelined one (upload, kernel and download of 48 MiB chunks rotating over three
+// streams) over its own host link when the slices are large. Nothing is exchanged between devices: results go back to host
+// memory. Shards beyond the device count share devices round robin ("virtual shards": what a one-GPU box can test).
+template <class T>
+int inverse_host_multi(int algo, int n, const void *hA, void *hAinv, size_t batch, int *info, int nshards, int kernel)
+{
+    if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
+    if (batch == 0) return MATINV_OK;
+    if (!hA || !hAinv) return fail(MATINV_ERR_ARG, "null host pointer");
+    std::vector<int> devs;
+    int rc = gfx950_devices(devs);
+    if (rc) return rc;
+    if (nshards <= 0) nshards = (int)devs.size();
+    if (nshards > 1024) return fail(MATINV_ERR_ARG, "nshards %d: at most 1024", nshards);
+    const size_t mult = n <= 8 ? 8 : (n <= 16 ? 4 : 1);
+    size_t per = (batch + (size_t)nshards - 1) / (size_t)nshards;
+    per = (per + mult - 1) / mult * mult;
+    const size_t mat = (size_t)n * n;
+    int home = 0;
+    (void)hipGetDevice(&home);
+    // page-lock both buffers ONCE for every device (adjacent shards share pages: per-shard registration would collide);
+    // small batches and aliasing buffers go through the plain staged copies instead
+    const bool pin = hA != hAinv && batch * mat * sizeof(T) >= ((size_t)64 << 20);
+    bool pinned = false;
+    if (pin) {
+        if (hipHostRegister(const_cast<void *>(hA), batch * mat * sizeof(T), hipHostRegisterPortable) == hipSuccess) {
+            if (hipHostRegister(hAinv, batch * mat * sizeof(T), hipHostRegisterPortable) == hipSuccess) pinned = true;
+            else (void)hipHostUnregister(const_cast<void *>(hA));
+        }
+        if (!pinned) (void)hipGetLastError();
+    }
+    struct Result {
+        int rc = MATINV_OK;
+        std::string msg;
+    };
+    std::vector<Result> res((size_t)nshards);
+    std::vector<std::thread> workers;
+    for (int g = 0; g < nshards; ++g) {
+        const size_t lo = std::min(batch, (size_t)g * per), hi = std::min(batch, lo + per);
+        if (hi == lo) continue;
+        const int dev = devs[(size_t)g % devs.size()];
+        workers.emplace_back([=, &res]() {
+            hipError_t e = hipSetDevice(dev);
+            int r = e == hipSuccess ? inverse_host<T>(algo, n, static_cast<const T *>(hA) + lo * mat, static_cast<T *>(hAinv) + lo * mat,
+                                                      hi - lo, info ? info + lo : nullptr, nullptr, kernel, true, pinned)
+                                    : fail_hip(e, "hipSetDevice");
+            res[(size_t)g].rc = r;
+            if (r != MATINV_OK) res[(size_t)g].msg = g_err;  // the worker's thread-local message
+        });
+    }
+    for (auto &t : workers) t.join();
+    if (pinned) {
+        (void)hipHostUnregister(const_cast<void *>(hA));
+        (void)hipHostUnregister(hAinv);
+    }
+    (void)hipSetDevice(home);
+    for (int g = 0; g < nshards; ++g)
+        if (res[(size_t)g].rc != MATINV_OK) return fail(res[(size_t)g].rc, "shard %d of %d: %s", g, nshards, res[(size_t)g].msg.c_str());
+    return MATINV_OK;
+}
+
 // Reference *_batched_device form: HOST-resident tables of DEVICE pointers (filled by batchedCudaMalloc,
 // /root/reference/src/helper.cu:103-118, so normally equally spaced by the pitch). Equally spaced tables are
 // passed as base + stride; anything else is staged into a device-side table that lives until the launch retires.
 template <class T>
-int inverse_table(int algo, int n, T *const *hostIn, T *const *hostOut, size_t batch, int chol_phases = 7)
+int inverse_table(int algo, int n, T *const *hostIn, T *const *hostOut, size_t batch, int chol_phases = 7,
+                  int kernel = MATINV_KERNEL_AUTO)
 {
     if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
     if (batch == 0) return MATINV_OK;
@@ -380,7 +470,7 @@ int inverse_table(int algo, int n, T *const *hostIn, T *const *hostOut, size_t b
     if (rc == MATINV_OK) {
         BatchRef<const T> A{hostIn[0], sIn, uIn ? nullptr : const_cast<const T *const *>(dTabIn)};
         BatchRef<T> X{hostOut[0], sOut, uOut ? nullptr : dTabOut};
-        rc = inverse_dispatch<T>(algo, n, A, X, batch, nullptr, nullptr, MATINV_KERNEL_AUTO, chol_phases);
+        rc = inverse_dispatch<T>(algo, n, A, X, batch, nullptr, nullptr, kernel, chol_phases);
     }
     if (dTabIn || dTabOut) {
         // rare path: the table must outlive the asynchronous launch
@@ -531,6 +621,12 @@ int gp_host(int n, const void *hA, const void *hB, const void *hC, const void *h
     return MATINV_OK;
 }
 
+template <class T>
+int lu_kernel(int n)
+{
+    return (n > 16 && (tilep_supports(n) || tilepw_supports(sizeof(T) == 8, n))) ? (int)MATINV_KERNEL_TILEP : (int)MATINV_KERNEL_AUTO;
+}
+
 // Reference error contract: message on stderr, then exit (include/helper_gpu.h:9-18, helper_cpu.h:12-21 there).
 void die_on(int rc, const char *fn)
 {
@@ -546,19 +642,36 @@ void die_on(int rc, const char *fn)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int matinv_abi_version(void) { return 1; }
+int matinv_abi_version(void) { return 2; }  // 2 (r03): + matinv_queue_*, matinv_batched_*, matinv_set_gj_policy, *_host_multi, matinv_allgather_*
+
+int matinv_set_gj_policy(int policy)
+{
+    if (policy != MATINV_GJ_NATURAL_FIRST && policy != MATINV_GJ_PIVOT && policy != MATINV_GJ_ADAPTIVE)
+        return fail(MATINV_ERR_ARG, "unknown Gauss-Jordan policy %d", policy);
+    return set_gj_policy(policy);
+}
+
+int matinv_device_count(void)
+{
+    std::vector<int> devs;
+    int rc = gfx950_devices(devs);
+    return rc ? rc : (int)devs.size();
+}
+
+int matinv_inverse_batched_host_multi(int algo, int dtype, int n, const void *hA, void *hAinv, size_t batch, int *info, int nshards)
+{
+    if (dtype == MATINV_F64) return inverse_host_multi<double>(algo, n, hA, hAinv, batch, info, nshards, MATINV_KERNEL_AUTO);
+    if (dtype == MATINV_F32) return inverse_host_multi<float>(algo, n, hA, hAinv, batch, info, nshards, MATINV_KERNEL_AUTO);
+    return fail(MATINV_ERR_ARG, "unknown dtype %d", dtype);
+}
 
 int matinv_release_cache(void)
 {
     int rc = check_device();
     if (rc) return rc;
-    int dev = 0;
-    hipMemPool_t pool;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipDeviceGetDefaultMemPool(&pool, dev);
-    if (e == hipSuccess) e = hipMemPoolTrimTo(pool, 0);
+    hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail_hip(e, "release cache");
+    scratch_release_device();
     return MATINV_OK;
 }
 const char *matinv_last_error(void) { return g_err; }
@@ -711,41 +824,45 @@ int matinv_inverse_batched_host(int algo, int dtype, int n, const void *hA, void
 // `handle` is ignored exactly as the reference's hand-written kernels ignore it.
 #define GJ MATINV_ALGO_GAUSS_JORDAN
 #define CH MATINV_ALGO_CHOLESKY
-#define REF_GPU(name, suffix, T, algo, logkey)                                                                       \
+#define KAUTO(T, n) MATINV_KERNEL_AUTO
+// the reference's LU entry points promise partial pivoting (cublas getrfBatched, src/gauss/inverse_gpu.cu:24-33): where the
+// MFMA tile family serves n they go straight to its pivoting kernel, whatever the Gauss-Jordan policy says
+#define KLU(T, n) lu_kernel<T>(n)
+#define REF_GPU(name, suffix, T, algo, logkey, KSEL)                                                                 \
     void name##suffix(void *handle, int n, T *As, T *aInvs, int batchSize)                                          \
     {                                                                                                                \
         (void)handle;                                                                                                \
         die_on(batchSize < 0 ? fail(MATINV_ERR_ARG, "negative batchSize") : inverse_host<T>(algo, n, As, aInvs,      \
-               (size_t)batchSize, nullptr, logkey), #name);                                                          \
+               (size_t)batchSize, nullptr, logkey, KSEL(T, n)), #name);                                              \
     }
-#define REF_DEV(name, suffix, T, algo, in, out, phases)                                                              \
+#define REF_DEV(name, suffix, T, algo, in, out, phases, KSEL)                                                        \
     void name##suffix(void *handle, int N, T **devAs, T **devAInvs, int batchSize)                                  \
     {                                                                                                                \
         (void)handle; (void)devAs; (void)devAInvs;                                                                   \
         die_on(batchSize < 0 ? fail(MATINV_ERR_ARG, "negative batchSize") : inverse_table<T>(algo, N, in, out,       \
-               (size_t)batchSize, phases), #name);                                                                   \
+               (size_t)batchSize, phases, KSEL(T, N)), #name);                                                       \
     }
 // log keys are the reference's TIMER_INIT names for each entry point
 #define REF_ALL(suffix, T)                                                                                           \
-    REF_GPU(inverse_gauss_batched_gpu, suffix, T, GJ, "inverse_gauss_batched_gpu")             /* batched_invert.cu:99 */ \
-    REF_GPU(inverse_lu_cuda_batched_gpu, suffix, T, GJ, "inverse_lu_cuda_batched_gpu")         /* gauss/inverse_gpu.cu:60 */ \
-    REF_GPU(inverse_cholesky_batched_gpu, suffix, T, CH, "decompose_cholesky_batched_gpu")     /* inverse_cholesky_gpu.cu:397 */ \
-    REF_GPU(inverse_cholesky_mm_batched_gpu, suffix, T, CH, "decompose_cholesky_mm_batched_gpu") /* :627 */          \
-    REF_GPU(inverse_cholesky_mm2_batched_gpu, suffix, T, CH, "cholesky_mm2_batched_gpu")       /* :699 */            \
-    REF_GPU(inverse_cholesky_stride_batched_gpu, suffix, T, CH, "inverse_cholesky_stride_batched_gpu") /* :189 */    \
-    REF_DEV(inverse_gauss_batched_device, suffix, T, GJ, devAs, devAInvs, 7)   /* declared inverse_gpu.h:10, never defined there */ \
-    REF_DEV(inverse_lu_cuda_batched_device, suffix, T, GJ, devAs, devAInvs, 7) /* gauss/inverse_gpu.cu:16; input kept intact here */ \
-    REF_DEV(inverse_cholesky_batched_device, suffix, T, CH, devAs, devAInvs, 7)        /* :323 */                    \
-    REF_DEV(inverse_cholesky_mm_batched_device, suffix, T, CH, devAs, devAInvs, 7)     /* :608 */                    \
-    REF_DEV(inverse_cholesky_mm2_batched_device, suffix, T, CH, devAs, devAInvs, 7)    /* :693 */                    \
+    REF_GPU(inverse_gauss_batched_gpu, suffix, T, GJ, "inverse_gauss_batched_gpu", KAUTO)             /* batched_invert.cu:99 */ \
+    REF_GPU(inverse_lu_cuda_batched_gpu, suffix, T, GJ, "inverse_lu_cuda_batched_gpu", KLU)         /* gauss/inverse_gpu.cu:60 */ \
+    REF_GPU(inverse_cholesky_batched_gpu, suffix, T, CH, "decompose_cholesky_batched_gpu", KAUTO)     /* inverse_cholesky_gpu.cu:397 */ \
+    REF_GPU(inverse_cholesky_mm_batched_gpu, suffix, T, CH, "decompose_cholesky_mm_batched_gpu", KAUTO) /* :627 */          \
+    REF_GPU(inverse_cholesky_mm2_batched_gpu, suffix, T, CH, "cholesky_mm2_batched_gpu", KAUTO)       /* :699 */            \
+    REF_GPU(inverse_cholesky_stride_batched_gpu, suffix, T, CH, "inverse_cholesky_stride_batched_gpu", KAUTO) /* :189 */    \
+    REF_DEV(inverse_gauss_batched_device, suffix, T, GJ, devAs, devAInvs, 7, KAUTO)   /* declared inverse_gpu.h:10, never defined there */ \
+    REF_DEV(inverse_lu_cuda_batched_device, suffix, T, GJ, devAs, devAInvs, 7, KLU) /* gauss/inverse_gpu.cu:16; input kept intact here */ \
+    REF_DEV(inverse_cholesky_batched_device, suffix, T, CH, devAs, devAInvs, 7, KAUTO)        /* :323 */                    \
+    REF_DEV(inverse_cholesky_mm_batched_device, suffix, T, CH, devAs, devAInvs, 7, KAUTO)     /* :608 */                    \
+    REF_DEV(inverse_cholesky_mm2_batched_device, suffix, T, CH, devAs, devAInvs, 7, KAUTO)    /* :693 */                    \
     /* stride family works in place on devAInvs (the *_gpu wrapper copies As there first, :213-216) */              \
-    REF_DEV(inverse_cholesky_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 7)     /* :182 */             \
-    REF_DEV(decompose_cholesky_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 1)   /* :96  */             \
-    REF_DEV(inverse_upper_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 2)        /* :137 */             \
-    REF_DEV(multiply_upper_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 4)       /* :175 */             \
+    REF_DEV(inverse_cholesky_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 7, KAUTO)     /* :182 */             \
+    REF_DEV(decompose_cholesky_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 1, KAUTO)   /* :96  */             \
+    REF_DEV(inverse_upper_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 2, KAUTO)        /* :137 */             \
+    REF_DEV(multiply_upper_stride_batched_device, suffix, T, CH, devAInvs, devAInvs, 4, KAUTO)       /* :175 */             \
     /* decompose: factor in place in devAs, strict upper triangle zeroed (:357-369, :616-624) */                    \
-    REF_DEV(decompose_cholesky_batched_device, suffix, T, CH, devAs, devAs, 1)                                       \
-    REF_DEV(decompose_cholesky_mm_batched_device, suffix, T, CH, devAs, devAs, 1)
+    REF_DEV(decompose_cholesky_batched_device, suffix, T, CH, devAs, devAs, 1, KAUTO)                                       \
+    REF_DEV(decompose_cholesky_mm_batched_device, suffix, T, CH, devAs, devAs, 1, KAUTO)
 
 REF_ALL(, double)
 REF_ALL(_f32, float)

@@ -512,10 +512,10 @@ static hipError_t launch_gj_blocked_small(int n, BatchRef<const T> A, BatchRef<T
     if (chunk > batch) chunk = batch;
     T *ws = nullptr;
     int *iws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), chunk * per_item, stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), chunk * per_item, stream);
     if (e != hipSuccess) return e;
-    e = hipMallocAsync(reinterpret_cast<void **>(&iws), chunk * (2 * (size_t)n + 1) * sizeof(int), stream);
-    if (e != hipSuccess) { (void)hipFreeAsync(ws, stream); return e; }
+    e = scratch_alloc(reinterpret_cast<void **>(&iws), chunk * (2 * (size_t)n + 1) * sizeof(int), stream);
+    if (e != hipSuccess) { (void)scratch_free(ws, stream); return e; }
     T *W0 = ws, *W1 = ws + chunk * (size_t)n * n, *Bbuf = W1 + chunk * (size_t)n * n;
     int *rowsrc = iws, *pivots = iws + chunk * (size_t)n, *status = pivots + chunk * (size_t)n;
     const unsigned threads = (unsigned)((n + 63) / 64 * 64);
@@ -534,7 +534,7 @@ static hipError_t launch_gj_blocked_small(int n, BatchRef<const T> A, BatchRef<T
         hipLaunchKernelGGL(matinv_bgj_finish<T>, dim3(g, b), dim3(256), 0, stream, cur, X, first, pivots, info, n, status);
     }
     e = hipGetLastError();
-    hipError_t e2 = hipFreeAsync(ws, stream), e3 = hipFreeAsync(iws, stream);
+    hipError_t e2 = scratch_free(ws, stream), e3 = scratch_free(iws, stream);
     return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
 }
 
@@ -543,7 +543,13 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
 {
     if (!blocked_gj_supports(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    if (n < 384) return launch_gj_blocked_small<T>(n, A, X, batch, info, stream);
+    // MATINV_BGJ_TWO_LEVEL_MIN: smallest n that takes the two-level scheme (A/B switch; default 384)
+    static const int two_level_min = []() {
+        const char *s = getenv("MATINV_BGJ_TWO_LEVEL_MIN");
+        const int v = s && *s ? atoi(s) : 0;
+        return v > 0 ? v : 384;
+    }();
+    if (n < two_level_min) return launch_gj_blocked_small<T>(n, A, X, batch, info, stream);
     // per item: two working copies, two block buffers (n x NB), the block's pivot rows (NB x n), a sub-panel's b strip
     const size_t per_item = (2 * (size_t)n * n + 3 * (size_t)BGJ_NB * n + (size_t)BGJ_PB * BGJ_NB) * sizeof(T);
     size_t chunk = blocked_workspace_cap() / per_item;  // bounded workspace, grid.y / grid.z limit
@@ -552,10 +558,10 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
     if (chunk > batch) chunk = batch;
     T *ws = nullptr;
     int *iws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), chunk * per_item, stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), chunk * per_item, stream);
     if (e != hipSuccess) return e;
-    e = hipMallocAsync(reinterpret_cast<void **>(&iws), chunk * (4 * (size_t)n + 1) * sizeof(int), stream);
-    if (e != hipSuccess) { (void)hipFreeAsync(ws, stream); return e; }
+    e = scratch_alloc(reinterpret_cast<void **>(&iws), chunk * (4 * (size_t)n + 1) * sizeof(int), stream);
+    if (e != hipSuccess) { (void)scratch_free(ws, stream); return e; }
     const size_t nn = (size_t)n * n, blk = (size_t)BGJ_NB * n, strip = (size_t)BGJ_PB * BGJ_NB;
     T *W0 = ws, *W1 = W0 + chunk * nn, *P0 = W1 + chunk * nn, *P1 = P0 + chunk * blk, *Bfull = P1 + chunk * blk,
       *Bin = Bfull + chunk * blk;
@@ -615,7 +621,7 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
         hipLaunchKernelGGL(matinv_bgj_finish<T>, dim3(g, b), dim3(256), 0, stream, cur, X, first, pivots, info, n, status);
     }
     e = hipGetLastError();
-    hipError_t e2 = hipFreeAsync(ws, stream), e3 = hipFreeAsync(iws, stream);
+    hipError_t e2 = scratch_free(ws, stream), e3 = scratch_free(iws, stream);
     return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
 }
 template hipError_t launch_gj_blocked<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);

@@ -271,10 +271,10 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
     if (chunk > batch) chunk = batch;
     T *W = nullptr;
     int *status = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&W), chunk * (size_t)ld * n * sizeof(T), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&W), chunk * (size_t)ld * n * sizeof(T), stream);
     if (e != hipSuccess) return e;
-    e = hipMallocAsync(reinterpret_cast<void **>(&status), chunk * sizeof(int), stream);
-    if (e != hipSuccess) { (void)hipFreeAsync(W, stream); return e; }
+    e = scratch_alloc(reinterpret_cast<void **>(&status), chunk * sizeof(int), stream);
+    if (e != hipSuccess) { (void)scratch_free(W, stream); return e; }
     for (size_t first = 0; first < batch; first += chunk) {
         const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
         const T *a_ = As + first * n, *B_ = Bs + first * (size_t)n * n, *c_ = Cs + first * n, *d_ = Ds ? Ds + first * n : nullptr;
@@ -289,7 +289,7 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
                            out + first, info ? info + first : nullptr, n, ld, status);
     }
     e = hipGetLastError();
-    hipError_t e2 = hipFreeAsync(W, stream), e3 = hipFreeAsync(status, stream);
+    hipError_t e2 = scratch_free(W, stream), e3 = scratch_free(status, stream);
     return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
 }
 template hipError_t launch_gp_blocked<double>(int, const double *, const double *, const double *, const double *,
@@ -396,10 +396,10 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     if (chunk > batch) chunk = batch;
     T *W = nullptr;
     int *status = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&W), chunk * (size_t)ld * n * sizeof(T), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&W), chunk * (size_t)ld * n * sizeof(T), stream);
     if (e != hipSuccess) return e;
-    e = hipMallocAsync(reinterpret_cast<void **>(&status), chunk * sizeof(int), stream);
-    if (e != hipSuccess) { (void)hipFreeAsync(W, stream); return e; }
+    e = scratch_alloc(reinterpret_cast<void **>(&status), chunk * sizeof(int), stream);
+    if (e != hipSuccess) { (void)scratch_free(W, stream); return e; }
     for (size_t first = 0; first < batch; first += chunk) {
         const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
         hipLaunchKernelGGL(matinv_binv_init<T>, dim3(64, b), dim3(BGP_THREADS), 0, stream, A, first, W, n, ld, status);
@@ -413,7 +413,7 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
                            g, b);
     }
     e = hipGetLastError();
-    hipError_t e2 = hipFreeAsync(W, stream), e3 = hipFreeAsync(status, stream);
+    hipError_t e2 = scratch_free(W, stream), e3 = scratch_free(status, stream);
     return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
 }
 template hipError_t launch_chol_blocked<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);

@@ -4,7 +4,22 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "../../include/matinv.h"
+
 namespace matinv {
+
+// (batch << 32) | rejected of a natural-order launch, stored by the work-list kernel behind it into pinned host memory
+typedef unsigned long long hint_t;
+
+// thread-local error message behind matinv_last_error(); returns `code` (abi.hip)
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail_hip(hipError_t e, const char *what);
+
+// Device scratch of the launchers: blocks cached per (device, stream), reused on their own stream only (scratch.hip)
+hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t stream);
+hipError_t scratch_free(void *p, hipStream_t stream);
+void scratch_retire_stream(hipStream_t stream);  // after synchronising a stream that is about to be destroyed
+void scratch_release_device();                   // after hipDeviceSynchronize: hipFree everything not in use
 
 // Where matrix k of a batch lives: either base + k*stride, or table[k] (the reference's
 // "array of device pointers" form, /root/reference/src/helper.cu:103-118).
@@ -166,13 +181,13 @@ hipError_t launch_gj_tilep<float>(int n, BatchRef<const float> A, BatchRef<float
 // (bad_count, bad_list), zeroed by the caller; hint_out (pinned host memory, may be null) receives the list length
 template <class T>
 hipError_t launch_gj_tilep_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count, const int *in_list,
-                                    int *bad_count, int *bad_list, int *info, hipStream_t stream, int *hint_out);
+                                    int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out);
 template <>
 hipError_t launch_gj_tilep_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
-                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, int *hint_out);
+                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out);
 template <>
 hipError_t launch_gj_tilep_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
-                                           const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, int *hint_out);
+                                           const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out);
 const char *name_gj_tilep(bool f64, int n);
 // four wavefronts per matrix, 64 < n <= 128 (tilep4_kernels.hip)
 template <class T>
@@ -183,16 +198,17 @@ template <>
 hipError_t launch_gj_tilep4<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
 template <class T>
 hipError_t launch_gj_tilep4_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count, const int *in_list,
-                                     int *bad_count, int *bad_list, int *info, hipStream_t stream, int *hint_out);
+                                     int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out);
 template <>
 hipError_t launch_gj_tilep4_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
                                              const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                             int *hint_out);
+                                             hint_t *hint_out);
 template <>
 hipError_t launch_gj_tilep4_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
                                             const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                            int *hint_out);
+                                            hint_t *hint_out);
 const char *name_gj_tilep4(bool f64, int n);
+int tilep_variant();  // MATINV_TILEP_WAVES: 0 = default, 1 = "col" (tilepw for 64 < n <= 128), 2 = "blk" (tilepb) -- A/B switch
 // one wavefront per tile column, 128 < n <= 192 (f64) / 256 (f32), general matrices (tilepw_kernels.hip)
 bool tilepw_supports(bool f64, int n);
 template <class T>
@@ -203,14 +219,26 @@ template <>
 hipError_t launch_gj_tilepw<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
 template <class T>
 hipError_t launch_gj_tilepw_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count, const int *in_list,
-                                     int *info, hipStream_t stream, int *hint_out);
+                                     int *info, hipStream_t stream, hint_t *hint_out);
 template <>
 hipError_t launch_gj_tilepw_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
-                                             const int *in_list, int *info, hipStream_t stream, int *hint_out);
+                                             const int *in_list, int *info, hipStream_t stream, hint_t *hint_out);
 template <>
 hipError_t launch_gj_tilepw_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
-                                            const int *in_list, int *info, hipStream_t stream, int *hint_out);
+                                            const int *in_list, int *info, hipStream_t stream, hint_t *hint_out);
 const char *name_gj_tilepw(bool f64, int n);
+// one wavefront per tile column, one tile column (16 pivots) per workgroup barrier, 64 < n <= 192 (f64) / 256 (f32)
+// (tilepb_kernels.hip); in_count / in_list: work-list form
+template <class T>
+hipError_t launch_gj_tilepb(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
+                            const int *in_count = nullptr, const int *in_list = nullptr, hint_t *hint_out = nullptr);
+template <>
+hipError_t launch_gj_tilepb<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream,
+                                    const int *in_count, const int *in_list, hint_t *hint_out);
+template <>
+hipError_t launch_gj_tilepb<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream,
+                                   const int *in_count, const int *in_list, hint_t *hint_out);
+const char *name_gj_tilepb(bool f64, int n);
 // second-generation natural-order tile kernel, n <= 64 (tilen_kernels.hip): enqueue only, the caller owns the work list
 template <class T>
 hipError_t enqueue_gj_tilen(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
@@ -229,7 +257,9 @@ struct TileStats {
 };
 TileStats tile_stats();
 bool tile_policy_use_pivot(bool f64, int nt);
-int *tile_policy_record(bool f64, int nt, size_t batch);
+hint_t *tile_policy_record(bool f64, int nt, size_t batch);
+int gj_policy();                // a matinv_gj_policy (include/matinv.h)
+int set_gj_policy(int policy);  // returns the previous one
 
 const char *name_gj_rowlane(bool f64, int n);
 const char *name_gj_tile(bool f64, int n);

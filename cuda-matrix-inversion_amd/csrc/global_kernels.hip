@@ -254,11 +254,11 @@ hipError_t launch_chol_global(int n, BatchRef<const T> A, BatchRef<T> X, size_t 
     if (!global_family_supports<T>(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     T *ws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), batch * (size_t)n * n * sizeof(T), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), batch * (size_t)n * n * sizeof(T), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(matinv_chol_global<T>, dim3((unsigned)batch), dim3(GL_THREADS), 0, stream, A, X, info, n, ws);
     e = hipGetLastError();
-    hipError_t e2 = hipFreeAsync(ws, stream);
+    hipError_t e2 = scratch_free(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 
@@ -269,12 +269,12 @@ hipError_t launch_gp_global(int n, const T *As, const T *Bs, const T *Cs, const 
     if (!global_family_supports<T>(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     T *ws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), batch * (size_t)n * n * sizeof(T), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), batch * (size_t)n * n * sizeof(T), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(matinv_gp_global<T>, dim3((unsigned)batch), dim3(GL_THREADS), 0, stream, As, Bs, Cs, Ds, Es, out, info,
                        n, ws);
     e = hipGetLastError();
-    hipError_t e2 = hipFreeAsync(ws, stream);
+    hipError_t e2 = scratch_free(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 

@@ -182,11 +182,11 @@ hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T 
     if (!gp_tile_supports(sizeof(T) == 8, n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
     if (e != hipSuccess) {
-        (void)hipFreeAsync(ws, stream);
+        (void)scratch_free(ws, stream);
         return e;
     }
     const int nt = (n + 15) / 16;
@@ -223,7 +223,7 @@ hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T 
 #undef GP_LAUNCH32
     e = hipGetLastError();
     if (e == hipSuccess) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
-    hipError_t e2 = hipFreeAsync(ws, stream);
+    hipError_t e2 = scratch_free(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 }  // namespace matinv

@@ -133,6 +133,7 @@ int matinv_queue_destroy(matinv_queue *q)
     for (hipStream_t s : q->streams)
         if (s) {
             (void)hipStreamSynchronize(s);
+            scratch_retire_stream(s);  // its cached gather batches may serve any stream of the device from now on
             (void)hipStreamDestroy(s);
         }
     for (hipEvent_t ev : q->done)
@@ -265,7 +266,7 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
                 // 256-byte aligned sub-buffers of one stream-ordered allocation
                 auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
                 const size_t total = one_run ? al(sc) * 2 : al(vec) * 3 + al(mat) + al(sc) * 3;
-                e = hipMallocAsync(reinterpret_cast<void **>(&L.staging), total, stream_of(b));
+                e = scratch_alloc(reinterpret_cast<void **>(&L.staging), total, stream_of(b));
                 if (e != hipSuccess) break;
                 char *p = L.staging;
                 if (!one_run) {
@@ -319,7 +320,7 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
         }
         if (e == hipSuccess) {
             memcpy(q->host_tab, tab.data(), tab.size() * sizeof(Seg));
-            e = hipMallocAsync(reinterpret_cast<void **>(&dev_tab), tab.size() * sizeof(Seg), user);
+            e = scratch_alloc(reinterpret_cast<void **>(&dev_tab), tab.size() * sizeof(Seg), user);
             if (e == hipSuccess) e = hipMemcpyAsync(dev_tab, q->host_tab, tab.size() * sizeof(Seg), hipMemcpyHostToDevice, user);
             if (e == hipSuccess) e = hipEventRecord(q->tables_uploaded, user);
         }
@@ -336,10 +337,17 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
             forked[slot_of(L.bin)] = true;
             if (e != hipSuccess) break;
         }
+        // gridDim.y = segments of one launch: at most 65 535 (thousands of one-item submits of one n reach that), so a long
+        // table goes out in several launches
         auto segcopy = [&](size_t seg0, size_t segs, size_t typical_bytes) {
             unsigned slices = (unsigned)std::min<size_t>(64, std::max<size_t>(1, typical_bytes / (256 * 16 * 4)));
-            hipLaunchKernelGGL(matinv_segcopy, dim3(slices, (unsigned)segs), dim3(256), 0, s, dev_tab + seg0);
-            return hipGetLastError();
+            hipError_t es = hipSuccess;
+            for (size_t done = 0; done < segs && es == hipSuccess; done += 65535) {
+                const unsigned part = (unsigned)std::min<size_t>(65535, segs - done);
+                hipLaunchKernelGGL(matinv_segcopy, dim3(slices, part), dim3(256), 0, s, dev_tab + seg0 + done);
+                es = hipGetLastError();
+            }
+            return es;
         };
         if (L.in_segs) e = segcopy(L.in_seg0, L.in_segs, L.items * L.n * L.n * esz / std::max<size_t>(1, L.in_segs / 4));
         if (e != hipSuccess) break;
@@ -350,8 +358,15 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
             break;
         }
         if (L.out_segs) e = segcopy(L.out_seg0, L.out_segs, 0);
-        if (e == hipSuccess && L.staging) e = hipFreeAsync(L.staging, s);
+        if (L.staging) {
+            hipError_t ef = scratch_free(L.staging, s);
+            plan[li].staging = nullptr;
+            if (e == hipSuccess) e = ef;
+        }
     }
+    // a failed flush: the staging batches of the launches that never ran (or failed half way) go back to the pool too
+    for (Launch &L : plan)
+        if (L.staging) (void)scratch_free(L.staging, stream_of(L.bin)), L.staging = nullptr;
     for (int slot = 0; slot < 2; ++slot) {
         if (!forked[slot]) continue;
         hipError_t e2 = hipEventRecord(q->done[slot], q->streams[slot]);
@@ -360,7 +375,7 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
     }
     for (size_t b = 0; b < q->bins.size(); ++b) q->q[b].clear();
     if (dev_tab) {
-        hipError_t e2 = hipFreeAsync(dev_tab, user);  // after the join: every launch that reads it has been ordered before
+        hipError_t e2 = scratch_free(dev_tab, user);  // after the join: every launch that reads it has been ordered before
         if (e == hipSuccess) e = e2;
     }
     q->tickets = 0;

@@ -361,11 +361,11 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
         return n > 128 ? launch_gj_tilepw<T>(n, A, X, batch, info, stream) : launch_gj_tilep4<T>(n, A, X, batch, info, stream);
     // [0], [1] = counts; [2 .. batch+2) = rejected matrices; [batch+2 ..) = (Gauss-Jordan) the singular ones among them
     int *ws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (2 * batch + 2) * sizeof(int), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (2 * batch + 2) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, 2 * sizeof(int), stream);
     if (e != hipSuccess) {
-        (void)hipFreeAsync(ws, stream);
+        (void)scratch_free(ws, stream);
         return e;
     }
     const int nt = (n + 15) / 16;
@@ -419,7 +419,7 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
             e = launch_gj_tilepw_worklist<T>(n, A, X, batch, ws, ws + 2, info, stream, tile_policy_record(sizeof(T) == 8, nt, batch));
         }
     }
-    hipError_t e2 = hipFreeAsync(ws, stream);
+    hipError_t e2 = scratch_free(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 
@@ -440,11 +440,11 @@ hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T
     if (!(tile4_supports(n) || gp_tile4_wide_supports(sizeof(T) == 8, n))) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
     if (e != hipSuccess) {
-        (void)hipFreeAsync(ws, stream);
+        (void)scratch_free(ws, stream);
         return e;
     }
     const int nt = (n + 15) / 16;
@@ -479,7 +479,7 @@ hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T
 #undef GP4_LAUNCH
     e = hipGetLastError();
     if (e == hipSuccess && nt <= 8) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
-    hipError_t e2 = hipFreeAsync(ws, stream);
+    hipError_t e2 = scratch_free(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 }  // namespace matinv

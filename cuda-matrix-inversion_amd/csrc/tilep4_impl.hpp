@@ -22,6 +22,7 @@
 // /root/reference/src/gauss/batched_invert.cu:17-82 (the reference's sweep goes to n = 128, Makefile:202-220).
 #pragma once
 #include "tilep_impl.hpp"
+#include "gather_tree.inc"
 
 namespace matinv {
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ void gather_zero_tile_row2(typename TileGeo<T>::vec4 
 template <class T, int NT, bool FULL>
 __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
                                                T *panel2, T *bball, unsigned char *tab, int *bad_count, int *bad_list,
-                                               const int *in_count, const int *in_list, int *hint_out)
+                                               const int *in_count, const int *in_list, hint_t *hint_out)
 {
     static_assert(NT >= 5 && NT <= 8, "four wavefronts serve 64 < n <= 128");
     typedef TileGeo<T> G;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
     // work-list form (the matrices the natural-order four-wave kernel rejected): in_list[0 .. *in_count); its length goes
     // back to the launcher's natural / pivot guess through pinned host memory (see tilep_impl.hpp)
     const unsigned todo = in_count ? (unsigned)*in_count : batch;
-    if (hint_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint_out, (int)todo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (hint_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint_out, ((hint_t)batch << 32) | todo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (unsigned item = blockIdx.x; item < todo; item += gridDim.x) {
         const unsigned mat = in_list ? (unsigned)in_list[item] : item;
         const T *A = Ain.at_uniform(mat);
@@ -227,6 +228,7 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
                 const int pos = 4 * (s >> 4) + G::slot_r(loc);
                 const unsigned long long mask = 0xffffull << (16 * G::slot_q(loc));
                 const unsigned addr = bb_lane + (unsigned)(t * 16 * NC * (int)sizeof(T));
+#ifdef MATINV_GATHER_LINEAR
                 gather_zero_tile_row2<T, NT, 0>(acc, addr, pos, mask);
                 gather_zero_tile_row2<T, NT, 1>(acc, addr, pos, mask);
                 gather_zero_tile_row2<T, NT, 2>(acc, addr, pos, mask);
@@ -235,6 +237,15 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
                 if constexpr (NT > 5) gather_zero_tile_row2<T, NT, 5>(acc, addr, pos, mask);
                 if constexpr (NT > 6) gather_zero_tile_row2<T, NT, 6>(acc, addr, pos, mask);
                 if constexpr (NT > 7) gather_zero_tile_row2<T, NT, 7>(acc, addr, pos, mask);
+#else
+                // r03: blocks of three tile rows, each one asm statement with a binary branch tree over the slot index
+                // (gather_tree.inc): a skipped per-tile-row block of the r02 form cost ~75 cycles, ~600 per pivot row here
+                gather_tree_2x3<0>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], addr, pos, mask);
+                if constexpr (NT == 5) gather_tree_2x2<12>(acc[3][0], acc[3][1], acc[4][0], acc[4][1], addr, pos, mask);
+                if constexpr (NT >= 6) gather_tree_2x3<12>(acc[3][0], acc[3][1], acc[4][0], acc[4][1], acc[5][0], acc[5][1], addr, pos, mask);
+                if constexpr (NT == 7) gather_tree_2x1<24>(acc[6][0], acc[6][1], addr, pos, mask);
+                if constexpr (NT == 8) gather_tree_2x2<24>(acc[6][0], acc[6][1], acc[7][0], acc[7][1], addr, pos, mask);
+#endif
             }
             // pivot columns (owner only): zero in C, I_4 in B
             {
@@ -341,7 +352,7 @@ __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T
 template <int NT, bool FULL>
 __global__ __launch_bounds__(256, NT <= 7 ? 3 : 2) void matinv_gj_tilep4_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
                                                               unsigned batch, int *bad_count, int *bad_list, const int *in_count,
-                                                              const int *in_list, int *hint_out)
+                                                              const int *in_list, hint_t *hint_out)
 {
     __shared__ __attribute__((aligned(16))) double panel2[2 * 16 * NT * 4];
     __shared__ __attribute__((aligned(16))) double bball[4 * 4 * 32];
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(256, NT <= 7 ? 3 : 2) void matinv_gj_tilep4_f64(Bat
 template <int NT, bool FULL>
 __global__ __launch_bounds__(256, 3) void matinv_gj_tilep4_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n_rt,
                                                               unsigned batch, int *bad_count, int *bad_list, const int *in_count,
-                                                              const int *in_list, int *hint_out)
+                                                              const int *in_list, hint_t *hint_out)
 {
     __shared__ __attribute__((aligned(16))) float panel2[2 * 16 * NT * 4];
     __shared__ __attribute__((aligned(16))) float bball[4 * 4 * 32];
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(256, 3) void matinv_gj_tilep4_f32(BatchRef<const fl
 
 template <class T>
 static hipError_t enqueue_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *bad_count,
-                                 int *bad_list, const int *in_count, const int *in_list, int *hint_out)
+                                 int *bad_list, const int *in_count, const int *in_list, hint_t *hint_out)
 {
     const int nt = (n + 15) / 16;
     unsigned cap = 256u * 3u * tile_grid_rounds();
@@ -397,17 +408,17 @@ static hipError_t launch_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_
     if (n <= 64 || n > 128) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
     if (e != hipSuccess) {
-        (void)hipFreeAsync(ws, stream);
+        (void)scratch_free(ws, stream);
         return e;
     }
     e = enqueue_tilep4<T>(n, A, X, batch, info, stream, ws, ws + 1, nullptr, nullptr, nullptr);
     // singular input only: the pivoted LDS kernel reports the exact step and NaN-fills the output
     if (e == hipSuccess) e = launch_gj_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream);
-    hipError_t e2 = hipFreeAsync(ws, stream);
+    hipError_t e2 = scratch_free(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 
@@ -416,7 +427,7 @@ static hipError_t launch_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_
 template <class T>
 static hipError_t launch_tilep4_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count,
                                          const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                         int *hint_out)
+                                         hint_t *hint_out)
 {
     hipError_t e = enqueue_tilep4<T>(n, A, X, batch, info, stream, bad_count, bad_list, in_count, in_list, hint_out);
     if (e == hipSuccess) e = launch_gj_lds_worklist<T>(n, A, X, bad_count, bad_list, info, stream);

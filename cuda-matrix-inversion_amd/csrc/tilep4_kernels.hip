@@ -3,17 +3,34 @@
 
 namespace matinv {
 
+// MATINV_TILEP_WAVES (A/B switch): "col" = 64 < n <= 128 on the one-wavefront-per-tile-column kernel with a barrier every 4
+// columns (tilepw_impl.hpp; measured slower than the four-wave kernel of this file at every size: 3.6e6 against 4.1e6 inv/s at
+// 128^2 f64, 8.2e6 against 1.28e7 at 72^2), "blk" = every 64 < n <= 192 / 256 on the kernel with one barrier per tile column
+// (tilepb_impl.hpp)
+int tilep_variant()
+{
+    static const int v = []() {
+        const char *s = getenv("MATINV_TILEP_WAVES");
+        return !s ? 0 : (s[0] == 'c' ? 1 : (s[0] == 'b' ? 2 : 0));
+    }();
+    return v;
+}
+
 template <>
 hipError_t launch_gj_tilep4<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream)
 {
+    if (tilep_variant() == 2) return launch_gj_tilepb<double>(n, A, X, batch, info, stream);
+    if (tilep_variant() == 1) return launch_gj_tilepw<double>(n, A, X, batch, info, stream);
     return launch_tilep4<double>(n, A, X, batch, info, stream);
 }
 
 template <>
 hipError_t launch_gj_tilep4_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
                                             const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                            int *hint_out)
+                                            hint_t *hint_out)
 {
+    if (tilep_variant() == 2) return launch_gj_tilepb<double>(n, A, X, batch, info, stream, in_count, in_list, hint_out);
+    if (tilep_variant() == 1) return launch_gj_tilepw_worklist<double>(n, A, X, batch, in_count, in_list, info, stream, hint_out);
     return launch_tilep4_worklist<double>(n, A, X, batch, in_count, in_list, bad_count, bad_list, info, stream, hint_out);
 }
 

@@ -154,7 +154,7 @@ struct IntC {
 
 template <class T, int NT, bool FULL>
 __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
-                                              T *lds, unsigned char *tab, const int *in_count, const int *in_list, int *hint_out,
+                                              T *lds, unsigned char *tab, const int *in_count, const int *in_list, hint_t *hint_out,
                                               int *bad_count, int *bad_list)
 {
     typedef TileGeo<T> G;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
     const unsigned todo = in_count ? (unsigned)*in_count : batch;
     // work-list form: the length of the list is what the launcher's natural-order / pivot guess feeds on; it goes back to
     // the host through a store into pinned memory (no copy command in the stream, nobody waits for it)
-    if (hint_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint_out, (int)todo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (hint_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint_out, ((hint_t)batch << 32) | todo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (unsigned item = blockIdx.x; item < todo; item += gridDim.x) {
         const unsigned mat = in_list ? (unsigned)in_list[item] : item;
         const T *A = Ain.at_uniform(mat);
@@ -409,7 +409,7 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
 
 template <int NT, bool FULL>
 __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
-                                                            unsigned batch, const int *in_count, const int *in_list, int *hint_out,
+                                                            unsigned batch, const int *in_count, const int *in_list, hint_t *hint_out,
                                                             int *bad_count, int *bad_list)
 {
     __shared__ __attribute__((aligned(16))) double lds[256 + 4 * 16 * NT];
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f64(BatchRef<const doub
 
 template <int NT, bool FULL>
 __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n_rt,
-                                                            unsigned batch, const int *in_count, const int *in_list, int *hint_out,
+                                                            unsigned batch, const int *in_count, const int *in_list, hint_t *hint_out,
                                                             int *bad_count, int *bad_list)
 {
     __shared__ __attribute__((aligned(16))) float lds[256 + 4 * 16 * NT];
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f32(BatchRef<const floa
 // Singular matrices are appended to (bad_count, bad_list) for the ROW kernel.
 template <class T>
 static hipError_t enqueue_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
-                                const int *in_count, const int *in_list, int *hint_out, int *bad_count, int *bad_list)
+                                const int *in_count, const int *in_list, hint_t *hint_out, int *bad_count, int *bad_list)
 {
     const int nt = (n + 15) / 16;
     unsigned cap = 256u * 12u * tile_grid_rounds();
@@ -466,16 +466,16 @@ static hipError_t launch_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     if (n < 1 || n > 64) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
     if (e != hipSuccess) {
-        (void)hipFreeAsync(ws, stream);
+        (void)scratch_free(ws, stream);
         return e;
     }
     e = enqueue_tilep<T>(n, A, X, batch, info, stream, nullptr, nullptr, nullptr, ws, ws + 1);
     if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, ws, ws + 1, info, stream);
-    hipError_t e2 = hipFreeAsync(ws, stream);
+    hipError_t e2 = scratch_free(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 
@@ -484,7 +484,7 @@ static hipError_t launch_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 template <class T>
 static hipError_t launch_tilep_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count,
                                         const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                        int *hint_out)
+                                        hint_t *hint_out)
 {
     hipError_t e = enqueue_tilep<T>(n, A, X, batch, info, stream, in_count, in_list, hint_out, bad_count, bad_list);
     if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, bad_count, bad_list, info, stream);

@@ -16,6 +16,7 @@
 // Replaces, for general matrices of these sizes, the 2 n / 32 + 2 launches of the blocked path (blocked_gj_kernels.hip).
 #pragma once
 #include "tilep_impl.hpp"
+#include "gather_tree.inc"
 
 namespace matinv {
 
@@ -59,21 +60,34 @@ __device__ __forceinline__ void gather_zero_tile_row1(typename TileGeo<T>::vec4 
 #undef TPW_WZ64
 }
 
+// The gather of one pivot row for a wave that holds ONE tile column of NT tile rows: blocks of four tile rows, each ONE asm
+// statement that finds the (tile row, register) slot with a binary branch tree (gather_tree.inc; r03 -- the per-tile-row blocks
+// of gather_zero_tile_row1 above cost ~75 cycles each when skipped: ~600 cycles per pivot row at 8 tile rows).
+// MATINV_GATHER_LINEAR (compile time) keeps the r02 form for A/B measurements.
 template <class T, int NT, int TI>
 struct GatherAllRows {
     static __device__ __forceinline__ void run(typename TileGeo<T>::vec4 (&acc)[NT][1], unsigned addr, int pos, unsigned long long mask)
     {
+#ifdef MATINV_GATHER_LINEAR
         gather_zero_tile_row1<T, NT, TI>(acc, addr, pos, mask);
         if constexpr (TI + 1 < NT) GatherAllRows<T, NT, TI + 1>::run(acc, addr, pos, mask);
+#else
+        static_assert(TI % 4 == 0, "blocks of four tile rows");
+        if constexpr (NT - TI >= 4) gather_tree_1x4<4 * TI>(acc[TI][0], acc[TI + 1][0], acc[TI + 2][0], acc[TI + 3][0], addr, pos, mask);
+        else if constexpr (NT - TI == 3) gather_tree_1x3<4 * TI>(acc[TI][0], acc[TI + 1][0], acc[TI + 2][0], addr, pos, mask);
+        else if constexpr (NT - TI == 2) gather_tree_1x2<4 * TI>(acc[TI][0], acc[TI + 1][0], addr, pos, mask);
+        else gather_tree_1x1<4 * TI>(acc[TI][0], addr, pos, mask);
+        if constexpr (TI + 4 < NT) GatherAllRows<T, NT, TI + 4>::run(acc, addr, pos, mask);
+#endif
     }
 };
 
 template <class T, int NT>
 __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n, unsigned batch, T *panel2,
                                                T *bball, unsigned char *tab, T *aopl, int *pvl, const int *in_count, const int *in_list,
-                                               int *hint_out)
+                                               hint_t *hint_out)
 {
-    static_assert(NT >= 9 && NT <= 16, "one wavefront per tile column: 128 < n <= 256");
+    static_assert(NT >= 5 && NT <= 16, "one wavefront per tile column: 64 < n <= 256");
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
     constexpr int N = 16 * NT;
@@ -89,7 +103,7 @@ __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T
     // work-list form (the matrices the natural-order kernel of this size rejected): in_list[0 .. *in_count); its length goes
     // back to the launcher's natural / pivot guess through pinned host memory (see tilep_impl.hpp)
     const unsigned todo = in_count ? (unsigned)*in_count : batch;
-    if (hint_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint_out, (int)todo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (hint_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint_out, ((hint_t)batch << 32) | todo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (unsigned item = blockIdx.x; item < todo; item += gridDim.x) {
         const unsigned mat = in_list ? (unsigned)in_list[item] : item;
         const T *A = Ain.at_uniform(mat);
@@ -286,10 +300,10 @@ __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T
         column(IntC<2>(), 0);
         column(IntC<3>(), 0);
         column(IntC<4>(), 0);
-        column(IntC<5>(), 0);
-        column(IntC<6>(), 0);
-        column(IntC<7>(), 0);
-        column(IntC<8>(), 0);
+        if constexpr (NT > 5) column(IntC<5>(), 0);
+        if constexpr (NT > 6) column(IntC<6>(), 0);
+        if constexpr (NT > 7) column(IntC<7>(), 0);
+        if constexpr (NT > 8) column(IntC<8>(), 0);
         if constexpr (NT > 9) column(IntC<9>(), 0);
         if constexpr (NT > 10) column(IntC<10>(), 0);
         if constexpr (NT > 11) column(IntC<11>(), 0);
@@ -320,9 +334,13 @@ __device__ __forceinline__ void gj_tilepw_body(BatchRef<const T> Ain, BatchRef<T
     }
 }
 
+// workgroups per CU the register budget is declared for: NT > 8: one (the matrix fills most of the CU's register file);
+// NT <= 8 (64 < n <= 128): 64 accumulator VGPRs per lane at most -> four waves per SIMD = two to three matrices per CU
+constexpr int tilepw_waves_per_simd(int nt) { return nt > 8 ? 1 : 4; }
+
 template <int NT>
-__global__ __launch_bounds__(64 * NT, 1) void matinv_gj_tilepw_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n,
-                                                                  unsigned batch, const int *in_count, const int *in_list, int *hint_out)
+__global__ __launch_bounds__(64 * NT, tilepw_waves_per_simd(NT)) void matinv_gj_tilepw_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n,
+                                                                  unsigned batch, const int *in_count, const int *in_list, hint_t *hint_out)
 {
     __shared__ __attribute__((aligned(16))) double panel2[16 * NT * 4];       // the owner's panel, one row per lane back
     __shared__ __attribute__((aligned(16))) double aopl[2 * 16 * NT * 4];     // the finished panel = A operand, double buffered
@@ -333,8 +351,8 @@ __global__ __launch_bounds__(64 * NT, 1) void matinv_gj_tilepw_f64(BatchRef<cons
 }
 
 template <int NT>
-__global__ __launch_bounds__(64 * NT, 1) void matinv_gj_tilepw_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n,
-                                                                  unsigned batch, const int *in_count, const int *in_list, int *hint_out)
+__global__ __launch_bounds__(64 * NT, tilepw_waves_per_simd(NT)) void matinv_gj_tilepw_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n,
+                                                                  unsigned batch, const int *in_count, const int *in_list, hint_t *hint_out)
 {
     __shared__ __attribute__((aligned(16))) float panel2[16 * NT * 4];       // the owner's panel, one row per lane back
     __shared__ __attribute__((aligned(16))) float aopl[2 * 16 * NT * 4];     // the finished panel = A operand, double buffered
@@ -349,12 +367,13 @@ constexpr int tilepw_limit(bool f64) { return f64 ? 192 : 256; }
 // in_count / in_list != nullptr: work-list form (one round of resident workgroups; usually empty)
 template <class T>
 static hipError_t launch_tilepw(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
-                                const int *in_count = nullptr, const int *in_list = nullptr, int *hint_out = nullptr)
+                                const int *in_count = nullptr, const int *in_list = nullptr, hint_t *hint_out = nullptr)
 {
-    if (n <= 128 || n > tilepw_limit(sizeof(T) == 8)) return hipErrorInvalidValue;
+    if (n <= 64 || n > tilepw_limit(sizeof(T) == 8)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     const int nt = (n + 15) / 16;
-    const unsigned cap = in_list ? 256u : 256u * tile_grid_rounds();
+    const unsigned per_cu = nt > 8 ? 1u : (unsigned)(16 / nt);  // resident workgroups per CU at four waves per SIMD
+    const unsigned cap = in_list ? 256u * per_cu : 256u * per_cu * tile_grid_rounds();
     const unsigned grid = (unsigned)(batch < cap ? batch : cap);
     const unsigned b = (unsigned)batch;
 #define TPW_LAUNCH(NT_)                                                                                                \
@@ -364,6 +383,10 @@ static hipError_t launch_tilepw(int n, BatchRef<const T> A, BatchRef<T> X, size_
         hipLaunchKernelGGL((matinv_gj_tilepw_f32<NT_>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, in_count, in_list, hint_out);        \
     }
     switch (nt) {
+    case 5: TPW_LAUNCH(5) break;
+    case 6: TPW_LAUNCH(6) break;
+    case 7: TPW_LAUNCH(7) break;
+    case 8: TPW_LAUNCH(8) break;
     case 9: TPW_LAUNCH(9) break;
     case 10: TPW_LAUNCH(10) break;
     case 11: TPW_LAUNCH(11) break;

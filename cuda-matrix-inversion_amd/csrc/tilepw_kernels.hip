@@ -8,13 +8,15 @@ bool tilepw_supports(bool f64, int n) { return n > 128 && n <= tilepw_limit(f64)
 template <>
 hipError_t launch_gj_tilepw<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream)
 {
+    if (tilep_variant() == 2) return launch_gj_tilepb<double>(n, A, X, batch, info, stream);
     return launch_tilepw<double>(n, A, X, batch, info, stream);
 }
 
 template <>
 hipError_t launch_gj_tilepw_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
-                                            const int *in_list, int *info, hipStream_t stream, int *hint_out)
+                                            const int *in_list, int *info, hipStream_t stream, hint_t *hint_out)
 {
+    if (tilep_variant() == 2) return launch_gj_tilepb<double>(n, A, X, batch, info, stream, in_count, in_list, hint_out);
     return launch_tilepw<double>(n, A, X, batch, info, stream, in_count, in_list, hint_out);
 }
 

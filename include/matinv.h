@@ -69,6 +69,29 @@ typedef enum {
                                   pivoting, panel of 32 columns eliminated with one thread per row (automatic beyond the LDS limit) */
 } matinv_kernel;
 
+/* Gauss-Jordan, 16 < n <= 192 (f64) / 256 (f32): which MFMA tile kernel a launch uses (process-wide, atomic; default
+ * MATINV_GJ_NATURAL_FIRST, or the environment's MATINV_GJ_POLICY=natural|pivot|adaptive read at the first launch).
+ *   NATURAL_FIRST  the natural-order kernel (pivots verified, not searched: the fast path of dominant / SPD batches); a
+ *                  matrix it rejects is redone by the pivoting kernel in the same stream. The result of a matrix depends
+ *                  on that matrix alone: repeatable bit for bit, identical for a sharded and an unsharded batch.
+ *   PIVOT          straight to the kernel with partial pivoting inside the MFMA sweep (general matrices at full speed; also
+ *                  per-matrix deterministic). The reference's LU names (inverse_lu_cuda_batched_*) always take it.
+ *   ADAPTIVE       chooses per launch from the reject count of the last completed natural-order launch of that size on
+ *                  that device: fastest on streams of like batches, but a matrix that both kernels accept may get either
+ *                  kernel's bits depending on what ran before. */
+typedef enum {
+    MATINV_GJ_NATURAL_FIRST = 0,
+    MATINV_GJ_PIVOT = 1,
+    MATINV_GJ_ADAPTIVE = 2
+} matinv_gj_policy;
+int matinv_set_gj_policy(int policy); /* returns the previous policy, or MATINV_ERR_ARG */
+
+/* THREAD SAFETY. Every entry point may be called concurrently from several host threads, on the same or on different devices
+ * (the device is the calling thread's current HIP device; matinv_last_error() is per thread). The library keeps no state
+ * between calls except: the GJ policy above (atomic), the ADAPTIVE policy's per-device counters (atomic), and the staging
+ * memory cached per (device, stream) inside the library (mutex-protected; matinv_release_cache). A matinv_queue is NOT internally locked: one
+ * thread at a time per queue. Launches on one stream execute in issue order, as HIP defines. */
+
 /* Invert `batch` matrices that are already resident in device memory.
  *   dA      in : batch matrices, matrix k at dA + k*strideA (elements). Never written.
  *   dAinv   out: matrix k at dAinv + k*strideInv. May be exactly dA with strideInv == strideA (in place:
@@ -107,6 +130,27 @@ int matinv_variance_batched(int dtype, int n, const void *dAs, const void *dBs, 
  * `info` is an optional host int[batch]. Synchronous. */
 int matinv_inverse_batched_host(int algo, int dtype, int n, const void *hA, void *hAinv, size_t batch, int *info);
 
+/* The same over SEVERAL devices of this process (one node): the batch is cut into `nshards` contiguous blocks of
+ * ceil(batch / nshards) matrices (rounded up to the per-wavefront packing of the small-n kernels: 8 for n <= 8, 4 for n <= 16),
+ * shard g runs on device g mod (number of gfx950 devices) on its own host thread with its own streams and its own host link
+ * -- no collective: the result goes back to host memory. nshards <= 0: one shard per visible device. More shards than
+ * devices is allowed ("virtual shards": several per device). The bits of every matrix are those of the single-device call.
+ * The reference-named *_batched_gpu entry points take this path with nshards = MATINV_DEVICES when that variable is > 1. */
+int matinv_inverse_batched_host_multi(int algo, int dtype, int n, const void *hA, void *hAinv, size_t batch, int *info,
+                                      int nshards);
+int matinv_device_count(void); /* visible gfx950 devices, or a negative status */
+
+/* Reassembly of device-resident shards over RCCL (librccl is opened at the first call: no link-time dependency). Every rank
+ * contributes `count` elements (pad the short tail shard) and receives nranks * count.
+ *   one process per GPU: matinv_comm_unique_id on rank 0 -> ship the 128 bytes to the others by any means ->
+ *                        matinv_comm_init_rank everywhere -> matinv_allgather_shards(comm, ...) on each rank's stream;
+ *   one process, several GPUs: matinv_allgather_local(ndev, devices, ...) (communicators created once and cached). */
+int matinv_comm_unique_id(void *id128);
+int matinv_comm_init_rank(void **comm, int nranks, const void *id128, int rank);
+int matinv_comm_destroy(void *comm);
+int matinv_allgather_shards(void *comm, int dtype, const void *dSend, void *dRecv, size_t count, void *stream);
+int matinv_allgather_local(int ndev, const int *devices, int dtype, const void *const *dSend, void *const *dRecv, size_t count);
+
 /* Host-pointer form of the fused pipeline (what gauss_bench times): H2D, one kernel, D2H of `batch` scalars.
  * Inputs are NOT modified (the reference CPU path destroys Bs and Cs, include/gauss_cpu.h:42 there). Synchronous. */
 int matinv_mean_batched_host(int dtype, int n, const void *hAs, const void *hBs, const void *hCs, const void *hDs,
@@ -124,12 +168,9 @@ int matinv_batched_free(void **devArrayPtr);
  * blocking. toDevice != 0: host -> device, else device -> host. Lets a plain-C caller stage data without HIP headers. */
 int matinv_memcpy_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, int toDevice);
 int matinv_device_synchronize(void);
-/* Gauss-Jordan, 16 < n <= 64: the tile family chooses per launch between its natural-order kernel (pivots verified, not
- * searched: the fast path of dominant / SPD batches; rejected matrices are redone by the pivoting kernel in the same stream)
- * and its pivoting kernel (true partial pivoting inside the MFMA sweep), from the reject count of the last completed
- * natural-order launch of that size. Counters since load: launches of either kind, and the reject count / batch of the last
- * natural-order launch whose count has come back (call matinv_device_synchronize first for an exact figure). Any pointer
- * may be NULL. MATINV_GJ_POLICY=natural|pivot pins the choice. */
+/* Counters of the tile family's Gauss-Jordan dispatch since load: launches that started with the natural-order kernel /
+ * went straight to the pivoting kernel, and -- MATINV_GJ_ADAPTIVE only -- the reject count / batch of the last natural-order
+ * launch whose count has come back (call matinv_device_synchronize first for an exact figure). Any pointer may be NULL. */
 int matinv_tile_stats(unsigned long long *natural_launches, unsigned long long *pivot_launches, unsigned long long *last_rejected,
                       unsigned long long *last_batch);
 
@@ -159,9 +200,12 @@ const char *matinv_queue_last_error(const matinv_queue *q);
 const char *matinv_last_error(void);
 int matinv_abi_version(void);
 
-/* The host-pointer entry points (and the work lists of the kernels) take their device staging memory from the current
- * device's default memory pool and leave it there between calls -- the reference's "allocate and free inside every call"
- * (src/gauss/batched_invert.cu:120-176) without its cost. This hands everything that is not in use back to the driver.
+/* The host-pointer entry points (and the work lists / workspaces of the kernels) take their device scratch memory from a cache
+ * inside the library, keyed by (device, stream) -- a block is reused on the stream it was first handed out on only, so
+ * stream order makes the reuse safe -- and leave it there between calls: the reference's "allocate and free inside every
+ * call" (src/gauss/batched_invert.cu:120-176) without its cost. The device's default memory pool is not touched. An
+ * allocation that fails for lack of memory empties the cache and is tried once more. This call synchronises the current
+ * device and hands everything that is not in use back to the driver.
  * Returns MATINV_OK, or MATINV_ERR_HIP / MATINV_ERR_NO_DEVICE. Never needed for correctness. */
 int matinv_release_cache(void);
 

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_native_abi():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/matinv.h but not exported"
     assert sorted(names) == sorted(pkg("_lib").NATIVE_NAMES)
-    assert L.matinv_abi_version() == 1
+    assert L.matinv_abi_version() == 2
 
 
 def test_library_exports_17_reference_names_both_precisions():

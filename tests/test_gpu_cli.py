@@ -116,3 +116,25 @@ def test_sweep_sizes_missing_from_the_reference_tree(tmp_path, n, k):
         assert [ln.split()[3] for ln in lines] == ["means_cpu", "variances_cpu", "means_gpu", "variances_gpu"]
         for ln in lines:
             assert float(ln.split()[7]) < tol, ln
+
+
+@pytest.mark.parametrize("exe", ["multi_test", "multi_test_f32"])
+@pytest.mark.parametrize("n,batch,shards", [(8, 1003, 3), (16, 1001, 2), (24, 500, 5), (64, 300, 4), (100, 67, 3), (150, 20, 2),
+                                            (64, 9000, 3)])
+def test_multi_device_host_path_in_c(exe, n, batch, shards):
+    """matinv_inverse_batched_host_multi from plain C: `shards` shards (virtual ones on a one-GPU box: round robin over the
+    devices there are), one host thread + hipSetDevice per shard, bit-identical to the single-device call on a mix of
+    dominant, mildly non-dominant and general matrices (SURVEY 8e determinism); 64 x 9000 f64 takes the page-locked,
+    pipelined three-stream path per shard."""
+    lines = run(exe, str(n), str(batch), str(shards))
+    assert lines[-1].startswith(f"multi_test n={n} batch={batch} shards={shards} ") and lines[-1].endswith("identical"), lines
+
+
+def test_reference_names_honour_matinv_devices():
+    """MATINV_DEVICES=3: inverse_gauss_batched_gpu itself shards over three (virtual) devices -- same bits (multi_test compares
+    it with matinv_inverse_batched_host); and inverse_bench runs unchanged under MATINV_DEVICES=1 and =2."""
+    lines = run("multi_test", "64", "500", "2", env={"MATINV_DEVICES": "3"})
+    assert lines[-1].endswith("identical"), lines
+    for nd in ("1", "2"):
+        lines = run("inverse_bench", os.path.join(REFDATA, "inverse_100_16x16"), "2", "4", "-csv", env={"MATINV_DEVICES": nd})
+        assert len(lines) == 6 and all(float(ln.split()[7]) < 5e-4 for ln in lines), lines

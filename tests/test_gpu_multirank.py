@@ -38,3 +38,45 @@ def test_bench_gpus2_runs_configs3_sharding():
     assert out["gather"]["n_ranks_seen"] == 2 and out["gather"]["allgather_ms"] > 0
     assert out["roofline"]["units_per_launch"] == 10001 and 0 < out["roofline"]["frac"] < 1
     assert out["value"] > 0 and out["unit"] == "inversions/s"
+
+
+def test_nccl_process_group_of_one_runs_the_bench_collectives():
+    """The nccl (= RCCL) branch of bench.py on the one GPU there is: a world-size-1 process group (MATINV_BENCH_FORCE_DIST=1),
+    so that init_process_group("nccl", device_id=...), the all-reduces and the all-gather of the result -- through
+    torch.distributed AND through the C ABI's own communicator (matinv_comm_* / matinv_allgather_shards) -- are at least
+    constructed and run before the driver's 8-GPU job meets them."""
+    for impl in ("torch", "c"):
+        p = _launch(1, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "5000",
+                    "--no-others", "--no-cpu-baseline", env={"MATINV_BENCH_FORCE_DIST": "1", "MATINV_GATHER": impl})
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["gather"]["backend"] == "nccl" and out["gather"]["n_ranks_seen"] == 1 and out["gather"]["impl"] == impl
+        assert out["gather"]["allgather_ms"] > 0 and out["gather"]["gather_equals_local_result"] is True
+
+
+def test_c_abi_allgather_single_process():
+    """matinv_allgather_local (one process, ncclCommInitAll over the visible devices -- one here) and the rank-wise form with
+    a communicator of one: the gathered buffer equals the shard."""
+    import ctypes
+    import importlib
+    import torch
+    lib = importlib.import_module("cuda-matrix-inversion_amd._lib")
+    L = lib.lib()
+    send = torch.rand(4096, dtype=torch.float64, device="cuda")
+    recv = torch.zeros_like(send)
+    devs = (ctypes.c_int * 1)(0)
+    sp = (ctypes.c_void_p * 1)(send.data_ptr())
+    rp = (ctypes.c_void_p * 1)(recv.data_ptr())
+    torch.cuda.synchronize()
+    lib.check(L.matinv_allgather_local(1, devs, lib.F64, sp, rp, send.numel()))
+    assert torch.equal(send, recv)
+    uid = (ctypes.c_ubyte * 128)()
+    lib.check(L.matinv_comm_unique_id(ctypes.cast(uid, ctypes.c_void_p)))
+    comm = ctypes.c_void_p()
+    lib.check(L.matinv_comm_init_rank(ctypes.byref(comm), 1, ctypes.cast(uid, ctypes.c_void_p), 0))
+    recv.zero_()
+    lib.check(L.matinv_allgather_shards(comm, lib.F64, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr()), send.numel(),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    lib.check(L.matinv_comm_destroy(comm))

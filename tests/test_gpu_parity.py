@@ -191,7 +191,15 @@ def test_natural_pass_two_rows_per_lane(n, dtype):
 def test_tile_family_pivots_inside_the_kernel(n, dtype):
     """General batches through the tile family: the first launch tries the natural order, every matrix it rejects is
     redone by the PIVOTING MFMA kernel in the same stream (not by the lane-per-row kernel), and from the next launch on
-    the batch goes to the pivoting kernel directly (adaptive dispatch, matinv_tile_stats)."""
+    the batch goes to the pivoting kernel directly (the opt-in MATINV_GJ_ADAPTIVE policy, matinv_tile_stats)."""
+    old_policy = api.set_gj_policy(api.GJ_ADAPTIVE)
+    try:
+        _adaptive_dispatch_body(n, dtype)
+    finally:
+        api.set_gj_policy(old_policy)
+
+
+def _adaptive_dispatch_body(n, dtype):
     a = general_batch(n, 300, seed=77 + n).astype(dtype)
     want, _ = oracle.inverse_batched(a.astype(np.float64), n, oracle.ALGO_GJ_PIVOT)
     cond = max(np.linalg.cond(m) for m in as_mats(a.astype(np.float64), n))
@@ -223,6 +231,70 @@ def test_tile_family_pivots_inside_the_kernel(n, dtype):
     assert s2["last_rejected"] == 0 and s2["last_batch"] == 64
     errb = np.linalg.norm(gotb.astype(np.float64) - wantb) / np.linalg.norm(wantb)
     assert errb < (1e-12 if dtype == np.float64 else 1e-4)
+
+
+def mild_batch(n, batch, seed=0, dtype=np.float64):
+    """R + R^T + 0.35 n I: symmetric, positive definite for n >= 8 but NOT diagonally dominant -- the natural-order kernels
+    accept some of these (multipliers between 1 and 4, where partial pivoting would have moved rows) and reject others."""
+    rng = np.random.default_rng(seed)
+    r = rng.random((batch, n, n))
+    return (r + r.transpose(0, 2, 1) + 0.35 * n * np.eye(n)).reshape(-1).astype(dtype)
+
+
+@pytest.mark.parametrize("n", [20, 24, 32, 48, 64, 80, 100, 128, 144, 192])
+def test_default_policy_is_a_function_of_the_matrix_alone(n):
+    """with the r02 adaptive dispatch a matrix that the natural-order kernel accepts but partial pivoting
+    would treat differently got either kernel's bits, depending on what had run before. The default policy since r03
+    (MATINV_GJ_NATURAL_FIRST) decides per matrix: the same batch gives the same bits (i) again, (ii) after general batches of
+    the same size have gone through, (iii) cut into shards of odd sizes, (iv) with its matrices in another order; and the
+    PIVOT policy agrees with it within the tolerance (different pivot sequences, same inverse)."""
+    assert api.set_gj_policy(api.GJ_NATURAL_FIRST) in (api.GJ_NATURAL_FIRST, api.GJ_PIVOT, api.GJ_ADAPTIVE)
+    batch = 301
+    a = mild_batch(n, batch, seed=31 + n)
+    d = dev(a)
+    first = api.inverse_batched(d, n, GJ, batch=batch).clone()
+    g = dev(general_batch(n, 64, seed=n))
+    for _ in range(3):
+        api.inverse_batched(g, n, GJ, batch=64)
+    again = api.inverse_batched(d, n, GJ, batch=batch)
+    assert torch.equal(first, again), "launch history changed the bits"
+    parts = [(0, 7), (7, 130), (130, 131), (131, batch)]
+    cut = torch.cat([api.inverse_batched(d[lo * n * n:hi * n * n], n, GJ, batch=hi - lo) for lo, hi in parts])
+    assert torch.equal(first, cut), "sharding changed the bits"
+    perm = torch.randperm(batch, generator=torch.Generator().manual_seed(n)).cuda()
+    shuffled = api.inverse_batched(d.view(batch, n * n)[perm].reshape(-1).contiguous(), n, GJ, batch=batch)
+    assert torch.equal(first.view(batch, n * n)[perm].reshape(-1), shuffled), "batch mates changed the bits"
+    want, winfo = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT)
+    assert not winfo.any()
+    cond = max(np.linalg.cond(m) for m in as_mats(a, n))
+    tol = max(1e-10, 1e-15 * cond * n)
+    assert rel_err(first.cpu().numpy(), want, n) < tol
+    api.set_gj_policy(api.GJ_PIVOT)
+    try:
+        piv = api.inverse_batched(d, n, GJ, batch=batch)
+        assert rel_err(piv.cpu().numpy(), want, n) < tol
+        assert torch.equal(piv, api.inverse_batched(d, n, GJ, batch=batch))
+    finally:
+        api.set_gj_policy(api.GJ_NATURAL_FIRST)
+
+
+def test_lu_names_take_the_pivoting_kernel():
+    """inverse_lu_cuda_batched_gpu (the reference's cuBLAS getrf/getri entry, src/gauss/inverse_gpu.cu:60-123: partial pivoting
+    is its contract) goes straight to the pivoting MFMA kernel: no natural-order launch is counted for it."""
+    n, batch = 64, 50
+    a = general_batch(n, batch, seed=3)
+    want, _ = oracle.inverse_batched(a, n, oracle.ALGO_GJ_PIVOT)
+    s0 = api.tile_stats()
+    out = np.empty_like(a)
+    api.inverse_lu_cuda_batched_gpu(n, a, out, batch)
+    s1 = api.tile_stats()
+    assert s1["natural_launches"] == s0["natural_launches"]
+    cond = max(np.linalg.cond(m) for m in as_mats(a, n))
+    assert rel_err(out, want, n) < max(1e-10, 1e-15 * cond * n)
+    api.inverse_gauss_batched_gpu(n, a, out, batch)  # the Gauss-Jordan name: natural order first, rejects to the pivoting kernel
+    s2 = api.tile_stats()
+    assert s2["natural_launches"] == s1["natural_launches"] + 1
+    assert rel_err(out, want, n) < max(1e-10, 1e-15 * cond * n)
 
 
 def test_simplemean_cholesky_golden(gold):
@@ -781,6 +853,38 @@ def test_full_size_properties(n, batch, algo):
     sub = a[idx].reshape(-1).cpu().numpy()
     want, _ = oracle.inverse_batched(sub, n, oracle.ALGO_GJ_PIVOT if algo == GJ else oracle.ALGO_CHOLESKY)
     assert rel_err(xm[idx].reshape(-1).cpu().numpy(), want, n) < 1e-10
+
+
+@pytest.mark.parametrize("n,batch", [(64, 100_000), (128, 25_000)])
+def test_full_size_properties_general(n, batch):
+    """The same at full size on GENERAL input (A ~ U(0,1)^(n x n), like the reference's tests/square_5_*.mats: every matrix
+    needs row exchanges): residual, info == 0, homogeneity, 64 oracle spot checks, and the launches the adaptive dispatch
+    makes one after the other (natural-order attempt + work list, then the pivoting kernel directly) bit-identical."""
+    g = torch.Generator(device="cuda").manual_seed(4321 + n)
+    a = torch.rand((batch, n, n), generator=g, dtype=torch.float64, device="cuda")
+    flat = a.reshape(-1)
+    info = torch.full((batch,), -7, dtype=torch.int32, device="cuda")
+    runs = []
+    for _ in range(3):  # the default policy (natural order first, rejects to the pivoting kernel) launch after launch
+        runs.append(api.inverse_batched(flat, n, GJ, info=info).clone())
+        torch.cuda.synchronize()
+        assert int((info != 0).sum()) == 0
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2]), "launch history changed the result bits"
+    x = runs[0]
+    xm = x.view(batch, n, n)
+    eye = torch.eye(n, dtype=torch.float64, device="cuda")
+    # cond(U(0,1)^(n x n)) reaches 1e5 .. 1e6 somewhere in 100 k draws: scale the bound per matrix with |X|
+    res = (torch.bmm(a, xm) - eye).abs().amax(dim=(1, 2))
+    scale = xm.abs().amax(dim=(1, 2)) * a.abs().amax(dim=(1, 2)) * n
+    assert float((res / scale).max()) < 1e-13, "residual |A X - I| beyond n * |A| * |X| * 1e-13"
+    quarter = api.inverse_batched(flat * 4.0, n, GJ)
+    assert torch.equal(quarter * 4.0, x), "inv(4A) must equal inv(A)/4 bit for bit"
+    idx = torch.arange(0, batch, batch // 64, device="cuda")[:64]
+    sub = a[idx].reshape(-1).cpu().numpy()
+    want, winfo = oracle.inverse_batched(sub, n, oracle.ALGO_GJ_PIVOT)
+    assert not winfo.any()
+    cond = max(np.linalg.cond(m) for m in as_mats(sub, n))
+    assert rel_err(xm[idx].reshape(-1).cpu().numpy(), want, n) < max(1e-10, 1e-15 * cond * n)
 
 
 @pytest.mark.parametrize("n,batch", [(8, 1003), (16, 1001), (32, 517), (64, 300), (100, 67), (128, 41), (200, 9)])

@@ -21,7 +21,12 @@ for ln in open(src):
         continue
     # a kernel may show up in several workloads' passes (the natural-order kernel also runs once, rejecting everything, in
     # the GENERAL workloads): keep, per kernel, the workload in which it moved the most bytes -- its full job
-    vals.setdefault((f[0].rsplit("_", 2)[0], f[4].strip()), {})[f[1]] = float(f[2])
+    wl, kern = f[0].rsplit("_", 2)[0], f[4].strip()
+    # a natural-order kernel seen in a GENERAL workload's pass rejected every matrix there (it read them and wrote nothing):
+    # not its job -- only the pivoting kernels are taken from those passes
+    if wl.endswith("g") and "tilep" not in kern:
+        continue
+    vals.setdefault((wl, kern), {})[f[1]] = float(f[2])
 path = os.path.join(os.path.dirname(src), "traffic.json")
 table = {}
 best = {}
@@ -38,7 +43,7 @@ for kern, (_, v) in best.items():
         continue
     rd, wr = 2.0 * v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
     n = {"matinv_gj_tile_f64": 16, "matinv_spd_tile_f64": 16, "matinv_gj_tile4_f64": 16, "matinv_gj_tilep_f64": 16,
-         "matinv_gj_tilep4_f64": 16}.get(kern.split("<")[0], 1) * int(m.group(1))
+         "matinv_gj_tilep4_f64": 16, "matinv_gj_tilepb_f64": 16, "matinv_gj_tilepw_f64": 16}.get(kern.split("<")[0], 1) * int(m.group(1))
     table[f"{kern}|n={n}"] = rd + wr
     table[f"{kern}|n={n}|detail"] = {"batch": batch, "read_bytes": rd, "write_bytes": wr,
                                      "algorithmic_bytes": batch * 2 * n * n * 8,
