@@ -509,6 +509,17 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             const char *s = getenv("MATINV_GP_TILE");  // A/B switch for profiling; default on
             return !(s && *s == '0');
         }();
+        static const bool use_spd = []() {
+            const char *s = getenv("MATINV_GP_SPD_TILE");  // A/B switch for profiling; default on
+            return !(s && *s == '0');
+        }();
+        if (use_tile && use_spd && gp_spd_tile_supports(sizeof(T) == 8, n)) {
+            hipError_t e = launch_gp_spd_tile<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
+                                                 variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
+                                                 static_cast<T *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
+            if (e != hipSuccess) return fail_hip(e, "kernel launch");
+            return MATINV_OK;
+        }
         if (use_tile && gp_tile_supports(sizeof(T) == 8, n)) {
             hipError_t e = launch_gp_tile<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
                                              static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
@@ -771,7 +782,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
         if (algo == MATINV_ALGO_GAUSS_JORDAN) {
             // the kernel that dominates: the rank-128 MFMA update of the two-level scheme from n = 384 (128 x 128 workgroup
             // tiles in fp32 when n rounded up to 128 wastes less than a fifth), the rank-32 VALU update below
-            if (n < 384) return f64 ? "matinv_bgj_update1<double>" : "matinv_bgj_update1<float>";
+            if (n < 224) return f64 ? "matinv_bgj_update1<double>" : "matinv_bgj_update1<float>";
             if (f64) return "matinv_bgj_update_mfma<double, false, 2>";
             return ((n + 127) / 128) * 128 <= 1.2 * n ? "matinv_bgj_update_mfma<float, false, 4>" : "matinv_bgj_update_mfma<float, false, 2>";
         }

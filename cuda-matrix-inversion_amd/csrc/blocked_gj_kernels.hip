@@ -543,11 +543,12 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
 {
     if (!blocked_gj_supports(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    // MATINV_BGJ_TWO_LEVEL_MIN: smallest n that takes the two-level scheme (A/B switch; default 384)
+    // MATINV_BGJ_TWO_LEVEL_MIN: smallest n that takes the two-level scheme (A/B switch). Default 224 since r03 (was 384):
+    // measured on general input, f64: 256^2 2.25e5 -> 2.55e5 inv/s, 320^2 1.18e5 -> 1.49e5; f32 320^2 1.80e5 -> 2.00e5; 200^2 equal
     static const int two_level_min = []() {
         const char *s = getenv("MATINV_BGJ_TWO_LEVEL_MIN");
         const int v = s && *s ? atoi(s) : 0;
-        return v > 0 ? v : 384;
+        return v > 0 ? v : 224;
     }();
     if (n < two_level_min) return launch_gj_blocked_small<T>(n, A, X, batch, info, stream);
     // per item: two working copies, two block buffers (n x NB), the block's pivot rows (NB x n), a sub-panel's b strip

@@ -272,6 +272,18 @@ template <class T>
 hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
                           int *info, hipStream_t stream);
 const char *name_gp_tile(bool f64, int n);
+// fused GP scalars on the SPD sweep of the Cholesky entry point (inverse in registers, folded, never stored): the sizes the
+// bordered form above no longer holds in one wavefront -- f64 80 < n <= 96, f32 96 < n <= 112 (tile_kernels.inc)
+bool gp_spd_tile_supports(bool f64, int n);
+template <class T>
+hipError_t launch_gp_spd_tile(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
+                              int *info, hipStream_t stream);
+template <>
+hipError_t launch_gp_spd_tile<double>(int n, const double *As, const double *Bs, const double *Cs, const double *Ds, const double *Es,
+                                      double *out, size_t batch, int *info, hipStream_t stream);
+template <>
+hipError_t launch_gp_spd_tile<float>(int n, const float *As, const float *Bs, const float *Cs, const float *Ds, const float *Es,
+                                     float *out, size_t batch, int *info, hipStream_t stream);
 const char *name_gj_lds(bool f64);
 const char *name_chol_lds(bool f64);
 const char *name_gp_lds(bool f64);

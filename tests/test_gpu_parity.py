@@ -764,7 +764,7 @@ def test_pipeline_fixtures(d, n, gold):
     assert np.abs(v - r["variances"]).mean() < 5e-5
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 7, 8, 9, 12, 16, 17, 33, 64, 65, 80, 81, 88, 96, 97, 100, 127, 128, 129])
+@pytest.mark.parametrize("n", [1, 2, 5, 7, 8, 9, 12, 16, 17, 33, 64, 65, 80, 81, 88, 96, 97, 100, 104, 112, 113, 127, 128, 129])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_pipeline_synthetic(n, dtype):
     rng = np.random.default_rng(n)
