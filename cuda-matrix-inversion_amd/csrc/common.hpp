@@ -101,6 +101,20 @@ template <class T>
 hipError_t enqueue_gj_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
                                int *work_list);
 const char *name_gj_rowlane2(bool f64, int n);
+// r03: the same kernel as the Cholesky entry point (lower triangle only, positive pivots) and as the fused mean / variance
+template <class T>
+hipError_t enqueue_spd_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
+                                int *work_list);
+template <class T>
+hipError_t launch_spd_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+template <class T>
+hipError_t launch_gp_rowlane2(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch, int *info,
+                              hipStream_t stream);
+bool rowlane2_spd_use(bool f64, int n);  // where these two replace the MFMA tile kernels (16 < n <= 25; MATINV_ROWLANE2_SPD=0: nowhere)
+const char *name_spd_rowlane2(bool f64, int n, bool gp);
+template <class T>
+hipError_t enqueue_gp_rowlane2(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch, int *info,
+                               hipStream_t stream, int *work_count, int *work_list);
 
 // blocked multi-launch Cholesky for the fused GP scalars at large n (blocked_gp_kernels.hip)
 template <class T>
@@ -115,6 +129,7 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 // rounds of resident workgroups in the grids of the MFMA-tile kernels (each workgroup strides over the batch);
 // MATINV_TILE_GRID_MULT overrides the default for A/B measurements (tile_kernels.hip)
 unsigned tile_grid_rounds();
+bool onewave_wide();  // r03: one-wavefront kernels on VGPRs + AGPRs beyond 256 registers (MATINV_ONEWAVE_WIDE=0: off)
 
 // blocked Gauss-Jordan with partial pivoting for large general matrices (blocked_gj_kernels.hip)
 bool blocked_gj_supports(int n);

@@ -158,7 +158,7 @@ __device__ __forceinline__ void gp_tile_body(const T *As, const T *Bs, const T *
 
 
 template <int NT, bool FULL>
-__global__ __launch_bounds__(64, 2) void matinv_gp_tile_f64(const double *As, const double *Bs, const double *Cs,
+__global__ __launch_bounds__(64, NT >= 6 ? 1 : 2) void matinv_gp_tile_f64(const double *As, const double *Bs, const double *Cs,
                                                            const double *Ds, const double *Es, double *out, int *info,
                                                            int n_rt, unsigned batch, int *work_count, int *work_list)
 {

@@ -13,8 +13,16 @@
 // factorisation that keeps 32 of 64 lanes busy: the job is HBM-bound either way (16 n^2 bytes per matrix), and this form
 // needs a quarter of the instructions per matrix.
 //
+// r03: the same kernel as the Cholesky entry point and the fused mean / variance for these sizes (MODE below): only the lower
+// triangle of the (symmetric) input is read -- an upper element comes from its mirror address --, the natural pivots are accepted
+// when they are all POSITIVE (they are the squares of the Cholesky diagonal; no multiplier test: the sweep is stable on SPD
+// input), rejected items go to the LDS Cholesky / LDS pipeline kernel through the same work list; the pipeline adds diag(c)
+// while loading and folds a^T M^-1 d out of the registers (24 or 32 DPP-broadcast FMAs per row, a 16-lane reduction, ONE scalar
+// written per item).
+//
 // Replaces, for these n, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95 (pivotRow :17-45,
-// normalizeRow :47-57, transform_matrix :59-82) like the other families.
+// normalizeRow :47-57, transform_matrix :59-82) like the other families; MODE 1 the Cholesky families of
+// src/inverse_cholesky_gpu.cu, MODE 2 calcluateMean / calcluateVariance (src/gauss_bench.cu:127-265,275-409).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -93,7 +101,9 @@ __device__ __forceinline__ float rl2_abs(float v) { return __builtin_fabsf(v); }
 
 // One step, K a literal: which register half holds the pivot row is a compile-time fact. Natural order, VERIFIED: a
 // multiplier above TAU (or NaN: zero / non-finite pivot) marks the matrix as rejected, nothing is exchanged here.
-template <int K, int NC, class T>
+enum { RL2_GJ = 0, RL2_SPD = 1, RL2_GP = 2 };
+
+template <int K, int NC, class T, int MODE = RL2_GJ>
 struct Rl2Step {
     static constexpr bool HK = K >= 16;
     static constexpr int LK = K & 15;
@@ -105,7 +115,8 @@ struct Rl2Step {
         const T inv = rcp_full(piv);
         const T nm_lo = me_lo ? (T)0 : -(lo[K] * inv);
         const T nm_hi = me_hi ? (T)0 : -(hi[K] * inv);
-        rej = rej || !(rl2_abs(nm_lo) <= (T)RL2_TAU) || !(rl2_abs(nm_hi) <= (T)RL2_TAU);
+        if constexpr (MODE == RL2_GJ) rej = rej || !(rl2_abs(nm_lo) <= (T)RL2_TAU) || !(rl2_abs(nm_hi) <= (T)RL2_TAU);
+        else rej = rej || !(piv > (T)0);  // SPD: leading principal minors positive (NaN fails)
         // eliminate: row r -= (a[r][K] / pivot) * row K for every other row; the pivot row keeps its values (unscaled until
         // the end). Column K itself is rewritten below.
         if constexpr (HK) {
@@ -130,10 +141,37 @@ constexpr int rl2_occupancy(size_t elem, int nc, bool full) { return elem == 8 ?
 
 // NC serves n = NC - 7 .. NC: only the last seven columns, rows and steps can be padding -- everything before them carries no
 // run-time predicate.
-template <class T, int NC, bool FULL>
+// acc += v[c] * (lane c % 16 of the matrix's row of 16 lanes)(dlo or dhi): the dot product of a register row with a vector that
+// lies one element per lane, the broadcast folded into the FMA like the elimination's
+template <int C, class T>
+__device__ __forceinline__ void rl2_dot_step(T &acc, T v, T dlo, T dhi)
+{
+    if constexpr (sizeof(T) == 8)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %[acc], %[d], %[v] row_newbcast:%[k] row_mask:0xf bank_mask:0xf"
+                     : [acc] "+v"(acc) : [d] "v"(C < 16 ? dlo : dhi), [v] "v"(v), [k] "n"(C & 15));
+    else
+        asm volatile("s_nop 1\n\tv_fmac_f32_dpp %[acc], %[d], %[v] row_newbcast:%[k] row_mask:0xf bank_mask:0xf"
+                     : [acc] "+v"(acc) : [d] "v"(C < 16 ? dlo : dhi), [v] "v"(v), [k] "n"(C & 15));
+}
+template <int C, int NC, class T>
+struct Rl2Dot {
+    static __device__ __forceinline__ void run(T (&acc)[4], const T (&row)[NC], T dlo, T dhi)
+    {
+        rl2_dot_step<C>(acc[C & 3], row[C], dlo, dhi);
+        if constexpr (C + 1 < NC) Rl2Dot<C + 1, NC, T>::run(acc, row, dlo, dhi);
+    }
+};
+
+template <class T>
+struct Rl2Gp {
+    const T *a, *c, *d, *e;  // d == nullptr: variance, out = e - a^T M^-1 a
+    T *out;
+};
+
+template <class T, int NC, bool FULL, int MODE = RL2_GJ>
 __global__ __launch_bounds__(RL2_THREADS, rl2_occupancy(sizeof(T), NC, FULL)) void matinv_gj_rowlane2(BatchRef<const T> Ain, BatchRef<T> Xout,
                                                                                               int *info, int n_rt, unsigned batch,
-                                                                                              int *work_count, int *work_list)
+                                                                                              int *work_count, int *work_list, Rl2Gp<T> gp)
 {
     constexpr int GPW = 4;       // matrices per wavefront
     constexpr int CMIN = NC - 7;  // smallest n this instantiation is launched for
@@ -158,19 +196,37 @@ __global__ __launch_bounds__(RL2_THREADS, rl2_occupancy(sizeof(T), NC, FULL)) vo
         // matrix slot beyond the batch work on a copy of the last matrix and store nothing.
         T lo[NC], hi[NC];
         const T *Alo = A + i, *Ahi = A + (hi_in ? 16 + i : i);
+        const int rhi = hi_in ? 16 + i : i;  // the upper row this lane really reads
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool col_in = FULL || c < CMIN || c < n;  // wave-uniform; literal for c < CMIN
             const int cc = col_in ? c : 0;
-            const T vl = Alo[cc * n], vh = Ahi[cc * n];
+            T vl, vh;
+            if constexpr (MODE == RL2_GJ) {
+                vl = Alo[cc * n], vh = Ahi[cc * n];
+            } else {
+                // only the LOWER triangle is read (the Cholesky contract): element (row, col) with col > row comes from its mirror
+                vl = A[(cc <= i) ? cc * n + i : i * n + cc];
+                vh = A[(cc <= rhi) ? cc * n + rhi : rhi * n + cc];
+            }
             lo[c] = col_in ? vl : (T)0;  // i < 16 <= c: never the diagonal
             hi[c] = (col_in && hi_in) ? vh : ((i + 16 == c) ? (T)1 : (T)0);
+        }
+        if constexpr (MODE == RL2_GP) {
+            // addDiagonal (gauss_bench.cu:38-43): this lane's rows i and i + 16
+            const T *vc = gp.c + (size_t)(valid ? mat : batch - 1) * n;
+            const T clo = vc[i], chi = vc[hi_in ? 16 + i : i];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (c < 16) lo[c] += (c == i) ? clo : (T)0;
+                else hi[c] += (c == i + 16 && hi_in) ? chi : (T)0;
+            }
         }
         bool rej = false;              // some multiplier of this lane's rows exceeded TAU (or was NaN)
         T rs_lo = (T)1, rs_hi = (T)1;  // 1 / pivot of the step in which the row was the pivot row
 
 #define RL2_RUN(K) \
-    if (FULL || K < CMIN || K < n) Rl2Step<K, NC, T>::run(lo, hi, i, rej, rs_lo, rs_hi);
+    if (FULL || K < CMIN || K < n) Rl2Step<K, NC, T, MODE>::run(lo, hi, i, rej, rs_lo, rs_hi);
         RL2_RUN(0) RL2_RUN(1) RL2_RUN(2) RL2_RUN(3) RL2_RUN(4) RL2_RUN(5) RL2_RUN(6) RL2_RUN(7)
         RL2_RUN(8) RL2_RUN(9) RL2_RUN(10) RL2_RUN(11) RL2_RUN(12) RL2_RUN(13) RL2_RUN(14) RL2_RUN(15)
         RL2_RUN(16) RL2_RUN(17) RL2_RUN(18) RL2_RUN(19) RL2_RUN(20) RL2_RUN(21) RL2_RUN(22) RL2_RUN(23)
@@ -181,7 +237,24 @@ __global__ __launch_bounds__(RL2_THREADS, rl2_occupancy(sizeof(T), NC, FULL)) vo
         // rejected by any row of the matrix (a DPP row = one matrix)
         const unsigned long long votes = __ballot(rej);
         const bool bad = ((votes >> (16 * g)) & 0xffffull) != 0;
-        if (!bad) {
+        if (MODE == RL2_GP && !bad) {
+            // s = sum_r a_r / pivot_r * (sum_c X'[r][c] d_c), X' = the rows before the deferred normalisation; padding rows and
+            // columns carry zeros in a and d
+            const size_t item = valid ? mat : batch - 1;
+            const T *va = gp.a + item * n, *vd = gp.d ? gp.d + item * n : va;
+            const T alo = va[i], ahi = hi_in ? va[16 + i] : (T)0;
+            const T dlo = vd[i], dhi = hi_in ? vd[16 + i] : (T)0;
+            T tl[4] = {0, 0, 0, 0}, th[4] = {0, 0, 0, 0};
+            Rl2Dot<0, NC, T>::run(tl, lo, dlo, dhi);
+            Rl2Dot<0, NC, T>::run(th, hi, dlo, dhi);
+            T s_ = alo * rs_lo * ((tl[0] + tl[1]) + (tl[2] + tl[3])) + ahi * rs_hi * ((th[0] + th[1]) + (th[2] + th[3]));
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) s_ += __shfl_xor(s_, off);  // the 16 lanes of the matrix
+            if (valid && i == 0) {
+                gp.out[mat] = gp.d ? s_ : gp.e[mat] - s_;
+                if (info) info[mat] = 0;
+            }
+        } else if (!bad) {
             // the deferred normalisation: every row was the pivot row of exactly one step
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -221,19 +294,55 @@ bool rowlane2_natural_use(bool f64, int n)
     return n <= 25;
 }
 
-template <class T, int NC, bool FULL>
+template <class T, int NC, bool FULL, int MODE = RL2_GJ>
 static hipError_t launch_rl2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
-                             int *work_list)
+                             int *work_list, Rl2Gp<T> gp = Rl2Gp<T>())
 {
     const size_t waves = (batch + 3) / 4;
     const size_t blocks = (waves + RL2_THREADS / 64 - 1) / (RL2_THREADS / 64);
     // persistent-style grid: what stays resident, every wave strides over the batch
     const unsigned resident = 256u * (unsigned)rl2_occupancy(sizeof(T), NC, FULL);
     const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
-    hipLaunchKernelGGL((matinv_gj_rowlane2<T, NC, FULL>), dim3(grid), dim3(RL2_THREADS), 0, stream, A, X, info, n, (unsigned)batch,
-                       work_count, work_list);
+    hipLaunchKernelGGL((matinv_gj_rowlane2<T, NC, FULL, MODE>), dim3(grid), dim3(RL2_THREADS), 0, stream, A, X, info, n, (unsigned)batch,
+                       work_count, work_list, gp);
     return hipGetLastError();
 }
+
+template <class T, int MODE>
+static hipError_t enqueue_rl2_mode(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
+                                   int *work_list, Rl2Gp<T> gp)
+{
+    if (!rowlane2_supports(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    // run-time n only (the compile-time-n instantiations of these modes spill under the occupancy the plain kernel is built for)
+    if (n <= 24) return launch_rl2<T, 24, false, MODE>(n, A, X, batch, info, stream, work_count, work_list, gp);
+    return launch_rl2<T, 32, false, MODE>(n, A, X, batch, info, stream, work_count, work_list, gp);
+}
+
+// the Cholesky entry point on this kernel: the items whose natural pivots are not all positive are appended to the work list
+// (-> LDS Cholesky, which reports the column)
+template <class T>
+hipError_t enqueue_spd_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
+                                int *work_list)
+{
+    return enqueue_rl2_mode<T, RL2_SPD>(n, A, X, batch, info, stream, work_count, work_list, Rl2Gp<T>());
+}
+template hipError_t enqueue_spd_rowlane2<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t, int *, int *);
+template hipError_t enqueue_spd_rowlane2<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t, int *, int *);
+
+// the fused mean / variance on this kernel (Ds == nullptr: variance); rejects -> work list (-> LDS pipeline kernel)
+template <class T>
+hipError_t enqueue_gp_rowlane2(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch, int *info,
+                               hipStream_t stream, int *work_count, int *work_list)
+{
+    BatchRef<const T> A{Bs, (size_t)n * n, nullptr};
+    BatchRef<T> X{nullptr, 0, nullptr};
+    return enqueue_rl2_mode<T, RL2_GP>(n, A, X, batch, info, stream, work_count, work_list, Rl2Gp<T>{As, Cs, Ds, Es, out});
+}
+template hipError_t enqueue_gp_rowlane2<double>(int, const double *, const double *, const double *, const double *, const double *, double *,
+                                                size_t, int *, hipStream_t, int *, int *);
+template hipError_t enqueue_gp_rowlane2<float>(int, const float *, const float *, const float *, const float *, const float *, float *, size_t,
+                                               int *, hipStream_t, int *, int *);
 
 // natural-order pass over the whole batch; the matrices it rejects are appended to work_list[0 .. *work_count)
 template <class T>
@@ -250,10 +359,63 @@ hipError_t enqueue_gj_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 template hipError_t enqueue_gj_rowlane2<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t, int *, int *);
 template hipError_t enqueue_gj_rowlane2<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t, int *, int *);
 
+// the two new entry points with their work lists: items this kernel rejects (not SPD) are finished by the LDS kernels, which
+// report the failing column
+template <class T>
+hipError_t launch_spd_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
+{
+    if (!rowlane2_supports(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e == hipSuccess) e = enqueue_spd_rowlane2<T>(n, A, X, batch, info, stream, ws, ws + 1);
+    if (e == hipSuccess) e = launch_chol_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream);
+    hipError_t e2 = scratch_free(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+template hipError_t launch_spd_rowlane2<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
+template hipError_t launch_spd_rowlane2<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
+
+template <class T>
+hipError_t launch_gp_rowlane2(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch, int *info,
+                              hipStream_t stream)
+{
+    if (!rowlane2_supports(n)) return hipErrorInvalidValue;
+    if (batch == 0) return hipSuccess;
+    int *ws = nullptr;
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
+    if (e == hipSuccess) e = enqueue_gp_rowlane2<T>(n, As, Bs, Cs, Ds, Es, out, batch, info, stream, ws, ws + 1);
+    if (e == hipSuccess) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
+    hipError_t e2 = scratch_free(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+template hipError_t launch_gp_rowlane2<double>(int, const double *, const double *, const double *, const double *, const double *, double *,
+                                               size_t, int *, hipStream_t);
+template hipError_t launch_gp_rowlane2<float>(int, const float *, const float *, const float *, const float *, const float *, float *, size_t,
+                                              int *, hipStream_t);
+
+// MATINV_ROWLANE2_SPD=0: the Cholesky entry point and the pipeline of these sizes stay on the MFMA tile kernels (A/B switch)
+bool rowlane2_spd_use(bool f64, int n)
+{
+    static const bool on = [] { const char *s = getenv("MATINV_ROWLANE2_SPD"); return !(s && *s == '0'); }();
+    return on && rowlane2_natural_use(f64, n);
+}
+
+const char *name_spd_rowlane2(bool f64, int n, bool gp)
+{
+    static thread_local char buf[80];
+    snprintf(buf, sizeof buf, "matinv_gj_rowlane2<%s, %d, false, %d>", f64 ? "double" : "float", n <= 24 ? 24 : 32, gp ? 2 : 1);
+    return buf;
+}
+
 const char *name_gj_rowlane2(bool f64, int n)
 {
     static thread_local char buf[80];
-    snprintf(buf, sizeof buf, "matinv_gj_rowlane2<%s, %d, %s>", f64 ? "double" : "float", n <= 24 ? 24 : 32,
+    snprintf(buf, sizeof buf, "matinv_gj_rowlane2<%s, %d, %s, 0>", f64 ? "double" : "float", n <= 24 ? 24 : 32,
              (n == 24 || n == 32) ? "true" : "false");
     return buf;
 }

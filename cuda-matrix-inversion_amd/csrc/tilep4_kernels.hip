@@ -6,7 +6,12 @@ namespace matinv {
 // MATINV_TILEP_WAVES (A/B switch): "col" = 64 < n <= 128 on the one-wavefront-per-tile-column kernel with a barrier every 4
 // columns (tilepw_impl.hpp; measured slower than the four-wave kernel of this file at every size: 3.6e6 against 4.1e6 inv/s at
 // 128^2 f64, 8.2e6 against 1.28e7 at 72^2), "blk" = every 64 < n <= 192 / 256 on the kernel with one barrier per tile column
-// (tilepb_impl.hpp)
+// (tilepb_impl.hpp).
+// (r03, measured and removed: the ONE-wavefront pivoting kernel of tilep_impl.hpp for 64 < n <= 96 with two rows per lane and the
+// 25 / 36 accumulator tiles in AGPRs -- one wave per SIMD, as launch_spd_tile does for the symmetric sweep. The pivot-row gather
+// is inline asm on the accumulator registers with "v" constraints, so hipcc shuttles whole tile rows between AGPRs and VGPRs
+// around every block: 156 B / 1 KB of scratch per lane at 5 x 5 / 6 x 6 tiles, 1.23e7 / 9.8e6 / 3.3e6 inv/s at 72^2 / 80^2 / 96^2
+// against 1.32e7 / 1.18e7 / 8.4e6 here.)
 int tilep_variant()
 {
     static const int v = []() {

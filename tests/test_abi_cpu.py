@@ -53,7 +53,11 @@ def test_kernel_selection_is_pure_host_logic():
     assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 192) == "matinv_gj_tile4_f64<12, false, 12, true>"
     assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, 1024) == api.KERNEL_BLOCKED
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 128) == "matinv_gj_tile4_f32<8, true, 4, false>"
-    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 100) == "matinv_gj_tile4_f64<7, false, 4, true>"
+    # r03: one wavefront per matrix on VGPRs + AGPRs up to 7 x 7 lower tiles (fp64 Cholesky), 8 x 8 in fp32
+    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 100) == "matinv_spd_tile_f64<7, false>"
+    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 120) == "matinv_gj_tile4_f64<8, false, 4, true>"
+    assert api.kernel_name(api.ALGO_CHOLESKY, api.F32, 128) == "matinv_spd_tile_f32<8, false>"
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 96) == "matinv_gj_tile4_f64<6, true, 2, false>"
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 512) == api.KERNEL_BLOCKED
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 150) == api.KERNEL_TILE   # one wavefront per tile column
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 192) == api.KERNEL_TILE
@@ -62,9 +66,10 @@ def test_kernel_selection_is_pure_host_logic():
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160) == "matinv_gj_tile4_f64<10, false, 10, false>"
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160, api.KERNEL_TILEP) == "matinv_gj_tilepw_f64<10>"
     # 16 < n <= 25: the natural-order pass of the tile family is the two-rows-per-lane kernel (csrc/rowlane2_kernels.hip)
-    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 24) == "matinv_gj_rowlane2<double, 24, true>"
-    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 20) == "matinv_gj_rowlane2<float, 24, false>"
-    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 25) == "matinv_gj_rowlane2<double, 32, false>"
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 24) == "matinv_gj_rowlane2<double, 24, true, 0>"
+    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 24) == "matinv_gj_rowlane2<double, 24, false, 1>"
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 20) == "matinv_gj_rowlane2<float, 24, false, 0>"
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 25) == "matinv_gj_rowlane2<double, 32, false, 0>"
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 26) == "matinv_gj_tile_f64<2, false, true>"
     assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 24) == "matinv_spd_tile_f64<2, false>"
     with pytest.raises(pkg("_lib").MatinvError):

@@ -87,6 +87,7 @@ for bits in (64, 32):
         src += function(bits, tiles, 1)
     for tiles in (1, 2, 3):
         src += function(bits, tiles, 2)
+
 src += "}  // namespace matinv\n"
 open(OUT, "w").write(src)
 print("wrote", os.path.normpath(OUT), len(src), "bytes")
