@@ -504,7 +504,7 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             return MATINV_OK;
         }
     }
-    if (rowlane2_spd_use(sizeof(T) == 8, n)) {  // 16 < n <= 25: the two-rows-per-lane kernel, inverse folded in registers (r03)
+    if (rowlane2_gp_use(sizeof(T) == 8, n)) {  // 16 < n <= 25: the two-rows-per-lane kernel, inverse folded in registers (r03)
         hipError_t er = launch_gp_rowlane2<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
                                               variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
                                               static_cast<T *>(out), batch, dInfo, static_cast<hipStream_t>(stream));

@@ -101,17 +101,12 @@ template <class T>
 hipError_t enqueue_gj_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
                                int *work_list);
 const char *name_gj_rowlane2(bool f64, int n);
-// r03: the same kernel as the Cholesky entry point (lower triangle only, positive pivots) and as the fused mean / variance
-template <class T>
-hipError_t enqueue_spd_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
-                                int *work_list);
-template <class T>
-hipError_t launch_spd_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+// r03: the same kernel as the fused mean / variance (positive pivots verified, a^T M^-1 d folded out of the registers)
 template <class T>
 hipError_t launch_gp_rowlane2(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch, int *info,
                               hipStream_t stream);
-bool rowlane2_spd_use(bool f64, int n);  // where these two replace the MFMA tile kernels (16 < n <= 25; MATINV_ROWLANE2_SPD=0: nowhere)
-const char *name_spd_rowlane2(bool f64, int n, bool gp);
+bool rowlane2_gp_use(bool f64, int n);  // where it replaces the MFMA tile pipeline kernel (16 < n <= 25; MATINV_ROWLANE2_GP=0: nowhere)
+const char *name_gp_rowlane2(bool f64, int n);
 template <class T>
 hipError_t enqueue_gp_rowlane2(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch, int *info,
                                hipStream_t stream, int *work_count, int *work_list);

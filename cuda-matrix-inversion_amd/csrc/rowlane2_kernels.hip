@@ -13,16 +13,17 @@
 // factorisation that keeps 32 of 64 lanes busy: the job is HBM-bound either way (16 n^2 bytes per matrix), and this form
 // needs a quarter of the instructions per matrix.
 //
-// r03: the same kernel as the Cholesky entry point and the fused mean / variance for these sizes (MODE below): only the lower
-// triangle of the (symmetric) input is read -- an upper element comes from its mirror address --, the natural pivots are accepted
-// when they are all POSITIVE (they are the squares of the Cholesky diagonal; no multiplier test: the sweep is stable on SPD
-// input), rejected items go to the LDS Cholesky / LDS pipeline kernel through the same work list; the pipeline adds diag(c)
-// while loading and folds a^T M^-1 d out of the registers (24 or 32 DPP-broadcast FMAs per row, a 16-lane reduction, ONE scalar
-// written per item).
+// r03: the same kernel as the fused mean / variance for these sizes (MODE RL2_GP): diag(c) is added while loading, the natural
+// pivots are accepted when they are all POSITIVE (they are the squares of the Cholesky diagonal; no multiplier test: the sweep is
+// stable on SPD input), rejected items go to the LDS pipeline kernel through the same work list, and a^T M^-1 d is folded out of
+// the register rows (24 or 32 DPP-broadcast FMAs per row, a 16-lane reduction, ONE scalar written per item): f64 7.1e8 / 5.0e8 /
+// 4.0e8 items/s at 17^2 / 20^2 / 24^2 against 3.0e8 on the 2 x 2-tile MFMA kernel. (MODE RL2_SPD, the Cholesky ENTRY POINT on this
+// kernel with lower-triangle-only loads -- an upper element from its mirror address --, was measured and is not dispatched: the
+// mirrored loads are uncoalesced, 3.7e8 / 2.9e8 inv/s at 20^2 / 24^2 f64 against 4.4e8 / 3.3e8 on the MFMA tile kernel.)
 //
 // Replaces, for these n, the 3n launches of /root/reference/src/gauss/batched_invert.cu:84-95 (pivotRow :17-45,
-// normalizeRow :47-57, transform_matrix :59-82) like the other families; MODE 1 the Cholesky families of
-// src/inverse_cholesky_gpu.cu, MODE 2 calcluateMean / calcluateVariance (src/gauss_bench.cu:127-265,275-409).
+// normalizeRow :47-57, transform_matrix :59-82) like the other families; MODE 2 calcluateMean / calcluateVariance
+// (src/gauss_bench.cu:127-265,275-409).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(RL2_THREADS, rl2_occupancy(sizeof(T), NC, FULL)) vo
             const bool col_in = FULL || c < CMIN || c < n;  // wave-uniform; literal for c < CMIN
             const int cc = col_in ? c : 0;
             T vl, vh;
-            if constexpr (MODE == RL2_GJ) {
+            if constexpr (MODE != RL2_SPD) {
                 vl = Alo[cc * n], vh = Ahi[cc * n];
             } else {
                 // only the LOWER triangle is read (the Cholesky contract): element (row, col) with col > row comes from its mirror
@@ -319,17 +320,6 @@ static hipError_t enqueue_rl2_mode(int n, BatchRef<const T> A, BatchRef<T> X, si
     return launch_rl2<T, 32, false, MODE>(n, A, X, batch, info, stream, work_count, work_list, gp);
 }
 
-// the Cholesky entry point on this kernel: the items whose natural pivots are not all positive are appended to the work list
-// (-> LDS Cholesky, which reports the column)
-template <class T>
-hipError_t enqueue_spd_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
-                                int *work_list)
-{
-    return enqueue_rl2_mode<T, RL2_SPD>(n, A, X, batch, info, stream, work_count, work_list, Rl2Gp<T>());
-}
-template hipError_t enqueue_spd_rowlane2<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t, int *, int *);
-template hipError_t enqueue_spd_rowlane2<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t, int *, int *);
-
 // the fused mean / variance on this kernel (Ds == nullptr: variance); rejects -> work list (-> LDS pipeline kernel)
 template <class T>
 hipError_t enqueue_gp_rowlane2(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch, int *info,
@@ -359,25 +349,8 @@ hipError_t enqueue_gj_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 template hipError_t enqueue_gj_rowlane2<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t, int *, int *);
 template hipError_t enqueue_gj_rowlane2<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t, int *, int *);
 
-// the two new entry points with their work lists: items this kernel rejects (not SPD) are finished by the LDS kernels, which
-// report the failing column
-template <class T>
-hipError_t launch_spd_rowlane2(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
-{
-    if (!rowlane2_supports(n)) return hipErrorInvalidValue;
-    if (batch == 0) return hipSuccess;
-    int *ws = nullptr;
-    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
-    if (e == hipSuccess) e = enqueue_spd_rowlane2<T>(n, A, X, batch, info, stream, ws, ws + 1);
-    if (e == hipSuccess) e = launch_chol_lds_worklist<T>(n, A, X, ws, ws + 1, info, stream);
-    hipError_t e2 = scratch_free(ws, stream);
-    return e != hipSuccess ? e : e2;
-}
-template hipError_t launch_spd_rowlane2<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
-template hipError_t launch_spd_rowlane2<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
-
+// the pipeline entry point with its work list: items this kernel rejects (not SPD) are finished by the LDS pipeline kernel,
+// which reports the failing column
 template <class T>
 hipError_t launch_gp_rowlane2(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch, int *info,
                               hipStream_t stream)
@@ -398,17 +371,17 @@ template hipError_t launch_gp_rowlane2<double>(int, const double *, const double
 template hipError_t launch_gp_rowlane2<float>(int, const float *, const float *, const float *, const float *, const float *, float *, size_t,
                                               int *, hipStream_t);
 
-// MATINV_ROWLANE2_SPD=0: the Cholesky entry point and the pipeline of these sizes stay on the MFMA tile kernels (A/B switch)
-bool rowlane2_spd_use(bool f64, int n)
+// MATINV_ROWLANE2_GP=0: the pipeline of these sizes stays on the MFMA tile kernel (A/B switch)
+bool rowlane2_gp_use(bool f64, int n)
 {
-    static const bool on = [] { const char *s = getenv("MATINV_ROWLANE2_SPD"); return !(s && *s == '0'); }();
+    static const bool on = [] { const char *s = getenv("MATINV_ROWLANE2_GP"); return !(s && *s == '0'); }();
     return on && rowlane2_natural_use(f64, n);
 }
 
-const char *name_spd_rowlane2(bool f64, int n, bool gp)
+const char *name_gp_rowlane2(bool f64, int n)
 {
     static thread_local char buf[80];
-    snprintf(buf, sizeof buf, "matinv_gj_rowlane2<%s, %d, false, %d>", f64 ? "double" : "float", n <= 24 ? 24 : 32, gp ? 2 : 1);
+    snprintf(buf, sizeof buf, "matinv_gj_rowlane2<%s, %d, false, 2>", f64 ? "double" : "float", n <= 24 ? 24 : 32);
     return buf;
 }
 

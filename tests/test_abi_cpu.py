@@ -67,7 +67,6 @@ def test_kernel_selection_is_pure_host_logic():
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160, api.KERNEL_TILEP) == "matinv_gj_tilepw_f64<10>"
     # 16 < n <= 25: the natural-order pass of the tile family is the two-rows-per-lane kernel (csrc/rowlane2_kernels.hip)
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 24) == "matinv_gj_rowlane2<double, 24, true, 0>"
-    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 24) == "matinv_gj_rowlane2<double, 24, false, 1>"
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 20) == "matinv_gj_rowlane2<float, 24, false, 0>"
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 25) == "matinv_gj_rowlane2<double, 32, false, 0>"
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 26) == "matinv_gj_tile_f64<2, false, true>"
