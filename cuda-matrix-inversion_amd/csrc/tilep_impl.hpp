@@ -32,6 +32,7 @@
 
 #include "tile_common.hpp"
 #include "wave_util.hpp"
+#include "gather_tree.inc"
 
 namespace matinv {
 
@@ -145,6 +146,16 @@ __device__ __forceinline__ void lane_rows_swap(double &a, double &b)
     lane_rows_swap<WIDE>(ahi, bhi);
     a = __longlong_as_double((long long)(((unsigned long long)ahi << 32) | alo));
     b = __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
+}
+
+// one tile row of the gather, NT tile columns wide, as ONE asm statement with a branch tree over the register (gather_tree.inc)
+template <class T, int NT, int TI>
+__device__ __forceinline__ void gather_row_tree(typename TileGeo<T>::vec4 (&acc)[NT][NT], unsigned addr, int pos, unsigned long long mask)
+{
+    if constexpr (NT == 1) gather_tree_1x1<4 * TI>(acc[TI][0], addr, pos, mask);
+    else if constexpr (NT == 2) gather_tree_2x1<4 * TI>(acc[TI][0], acc[TI][1], addr, pos, mask);
+    else if constexpr (NT == 3) gather_tree_3x1<4 * TI>(acc[TI][0], acc[TI][1], acc[TI][2], addr, pos, mask);
+    else gather_tree_4x1<4 * TI>(acc[TI][0], acc[TI][1], acc[TI][2], acc[TI][3], addr, pos, mask);
 }
 
 template <int V>
@@ -306,10 +317,20 @@ __device__ __forceinline__ void gj_tilep_body(BatchRef<const T> Ain, BatchRef<T>
                 const int pos = 4 * (s >> 4) + G::slot_r(loc);  // wave-uniform: 4 * tile row + register
                 const unsigned long long mask = 0xffffull << (16 * G::slot_q(loc));
                 const unsigned addr = bb_lane + (unsigned)(t * N * (int)sizeof(T));
+#ifdef MATINV_GATHER_LINEAR
                 gather_zero_tile_row<T, NT, 0>(acc, addr, pos, mask);
                 if constexpr (NT > 1) gather_zero_tile_row<T, NT, 1>(acc, addr, pos, mask);
                 if constexpr (NT > 2) gather_zero_tile_row<T, NT, 2>(acc, addr, pos, mask);
                 if constexpr (NT > 3) gather_zero_tile_row<T, NT, 3>(acc, addr, pos, mask);
+#else
+                // r03: inside a tile row the register is found with the branch tree of gather_tree.inc instead of a compare chain.
+                // (Finding the tile ROW with one wave-uniform C++ branch over the halves instead of NT skipped blocks was tried: the
+                // two paths meet with the accumulators in different registers and hipcc spills -- 272 B of scratch at 4 x 4 tiles.)
+                gather_row_tree<T, NT, 0>(acc, addr, pos, mask);
+                if constexpr (NT > 1) gather_row_tree<T, NT, 1>(acc, addr, pos, mask);
+                if constexpr (NT > 2) gather_row_tree<T, NT, 2>(acc, addr, pos, mask);
+                if constexpr (NT > 3) gather_row_tree<T, NT, 3>(acc, addr, pos, mask);
+#endif
             }
             // pivot columns: zero in C (the MFMA then leaves Aop there) -- placed here, it runs under the gather's LDS turn-around
             {

@@ -88,6 +88,10 @@ for bits in (64, 32):
     for tiles in (1, 2, 3):
         src += function(bits, tiles, 2)
 
+# one tile row, NT tile columns wide: the one-wavefront kernel of tilep_impl.hpp (NT <= 4)
+for bits in (64, 32):
+    for cols in (3, 4):
+        src += function(bits, 1, cols)
 src += "}  // namespace matinv\n"
 open(OUT, "w").write(src)
 print("wrote", os.path.normpath(OUT), len(src), "bytes")

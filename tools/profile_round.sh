@@ -13,6 +13,11 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $W -o trace -- python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench_default.json 2> $W/trace.err
 python3 $R/tools/rocprof_summary.py $W/trace_results.db "$TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3" > $OUT/${TAG}_bench_default_kernel_trace.txt
 
+# the headline workload alone: the default line above also launches the headline kernel on other batch sizes (end-to-end chunks,
+# residual checks), which pollutes its average; here every launch of it is one timed-size step
+rocprofv3 --kernel-trace --stats -d $W -o headline -- python3 $R/bench.py --steps 20 --warmup 5 --no-others --no-cpu-baseline > $OUT/${TAG}_bench_headline.json 2> $W/headline.err
+python3 $R/tools/rocprof_summary.py $W/headline_results.db "$TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-others --no-cpu-baseline (the headline workload alone: every launch of its kernel is one 100 000-matrix step)" > $OUT/${TAG}_bench_headline_kernel_trace.txt
+
 for w in gj64 gj16 gj24 gj32 chol64 gj128 gj64g gj32g gj128g; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c -d $W -o ${w}_$c -- python3 $R/bench.py --workload $w --steps 3 --warmup 2 --no-cpu-baseline --no-others > $W/${w}_$c.out 2>&1
