@@ -520,6 +520,15 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             const char *s = getenv("MATINV_GP_SPD_TILE");  // A/B switch for profiling; default on
             return !(s && *s == '0');
         }();
+        if constexpr (sizeof(T) == 8) {
+            if (use_tile && spd_tile2_supports(true, n)) {  // fp64 112 < n <= 128: two wavefronts, lower tiles only (r03)
+                hipError_t e = launch_gp_spd_tile2(n, static_cast<const double *>(a), static_cast<const double *>(B), static_cast<const double *>(c),
+                                                   variance ? nullptr : static_cast<const double *>(d), static_cast<const double *>(e_),
+                                                   static_cast<double *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
+                if (e != hipSuccess) return fail_hip(e, "kernel launch");
+                return MATINV_OK;
+            }
+        }
         if (use_tile && use_spd && gp_spd_tile_supports(sizeof(T) == 8, n)) {
             hipError_t e = launch_gp_spd_tile<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
                                                  variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),

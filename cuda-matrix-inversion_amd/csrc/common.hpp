@@ -285,6 +285,13 @@ const char *name_gp_tile(bool f64, int n);
 // fused GP scalars on the SPD sweep of the Cholesky entry point (inverse in registers, folded, never stored): the sizes the
 // bordered form above no longer holds in one wavefront -- f64 80 < n <= 96, f32 96 < n <= 112 (tile_kernels.inc)
 bool gp_spd_tile_supports(bool f64, int n);
+// two wavefronts per matrix, lower tiles only, fp64 112 < n <= 128: Cholesky entry point and fused pipeline (spd_tile2_kernels.hip);
+// MATINV_SPD_TILE2=0: off
+bool spd_tile2_supports(bool f64, int n);
+hipError_t launch_spd_tile2(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
+hipError_t launch_gp_spd_tile2(int n, const double *As, const double *Bs, const double *Cs, const double *Ds, const double *Es, double *out,
+                               size_t batch, int *info, hipStream_t stream);
+const char *name_spd_tile2(bool gp);
 template <class T>
 hipError_t launch_gp_spd_tile(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
                               int *info, hipStream_t stream);
