@@ -13,6 +13,8 @@
 // row tK it owns (W[I, K] = W[K, I]^T), barrier (the panel is double buffered), ONE wave -- they take turns -- solves the panel
 // (PanelSolve, SPD mode: A operand and the symmetric B operand) and publishes both through LDS, barrier, both waves prepare their
 // operands and issue their MFMAs. (First version: both waves solved redundantly, one barrier per step: 9.8e6 inv/s at 128^2.)
+// (Measured and not kept: ONE wave -- taking turns -- solving the panel and publishing the A operand and the symmetric B operand
+// through LDS, two barriers per step: Cholesky 128^2 9.8e6 -> 1.07e7 inv/s, pipeline 1.17e7 -> 1.04e7 items/s: a wash.)
 // GP = the fused mean / variance on the same sweep (see SpdGp in tile_kernels.inc): diag c added while loading, a^T M^-1 d folded
 // out of the accumulators of both waves, nothing stored.
 //
