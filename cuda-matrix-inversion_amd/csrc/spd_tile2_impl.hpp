@@ -10,9 +10,8 @@
 // garbage that is never staged, stored or folded -- 2 of 20 MFMAs wasted, no wave-dependent control flow): 160 accumulator
 // registers, two waves per SIMD, FOUR matrices per CU (the four-wave kernel: two), 40 MFMAs per block step and matrix instead of 64.
 // Per block step: the owner of the pivot tile column stages its part of the panel, every wave adds the transposed pieces of tile
-// row tK it owns (W[I, K] = W[K, I]^T), barrier (the panel is double buffered), ONE wave -- they take turns -- solves the panel
-// (PanelSolve, SPD mode: A operand and the symmetric B operand) and publishes both through LDS, barrier, both waves prepare their
-// operands and issue their MFMAs. (First version: both waves solved redundantly, one barrier per step: 9.8e6 inv/s at 128^2.)
+// row tK it owns (W[I, K] = W[K, I]^T), ONE workgroup barrier (the panel is double buffered), both waves solve the panel
+// redundantly (PanelSolve, SPD mode: A operand and the symmetric B operand), prepare their operands and issue their MFMAs.
 // (Measured and not kept: ONE wave -- taking turns -- solving the panel and publishing the A operand and the symmetric B operand
 // through LDS, two barriers per step: Cholesky 128^2 9.8e6 -> 1.07e7 inv/s, pipeline 1.17e7 -> 1.04e7 items/s: a wash.)
 // GP = the fused mean / variance on the same sweep (see SpdGp in tile_kernels.inc): diag c added while loading, a^T M^-1 d folded
@@ -55,8 +54,7 @@ struct Spd2Steps {
 
 template <bool GP>
 __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt, unsigned batch,
-                                               int *work_count, int *work_list, double *panel2, double *tbuf2, double *pub, int *pubbad,
-                                               Spd2Gp<double> gp)
+                                               int *work_count, int *work_list, double *panel2, double *tbuf2, Spd2Gp<double> gp)
 {
     typedef double T;
     typedef TileGeo<T> G;
@@ -64,7 +62,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
     constexpr int NT = 8, N = 16 * NT, NKB = 4 * NT, NL = 4;
     constexpr int TSTRIDE = 17;  // padded row stride of the 16 x 16 transpose buffers (one per wave)
     const int l = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0 or 1, in an SGPR: the solver role branches on it
+    const int w = threadIdx.x >> 6;  // wave-uniform: 0 or 1
     T *const tbuf = tbuf2 + w * (16 * TSTRIDE);
     int tjs[NL];
 #pragma unroll
@@ -129,29 +127,9 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
             if (kb > 4 * (NT - 1) && kb - 4 * (NT - 1) >= last_blocks) return;
             const T *const buf = panel2 + (kb & 1) * (N * 4);
             T aop[NT], bsym[NT];
-            // ONE wave solves the panel (the waves take turns) and publishes the A operand and the symmetric B operand, one value
-            // per lane and tile row, through LDS: the solve costs as much issue time as a wave's 20 MFMAs, and with four workgroups
-            // per CU the SIMDs are busy -- repeating it in both waves was 30 % of the kernel
-            if (w == (kb & 1)) {
-                PanelSolve<NT, true, T> ps;
+            PanelSolve<NT, true, T> ps;
 #pragma unroll
-                for (int s = 0; s < PanelSolve<NT, true, T>::NSTAGE; ++s) ps.stage(s, buf, kb, q, c, aop, bsym, bad);
-#pragma unroll
-                for (int ti = 0; ti < NT; ++ti) {
-                    pub[ti * 64 + l] = aop[ti];
-                    pub[(NT + ti) * 64 + l] = bsym[ti];
-                }
-                if (l == 0) *pubbad = bad != 0;
-            }
-            __syncthreads();
-            if (w != (kb & 1)) {
-#pragma unroll
-                for (int ti = 0; ti < NT; ++ti) {
-                    aop[ti] = pub[ti * 64 + l];
-                    bsym[ti] = pub[(NT + ti) * 64 + l];
-                }
-                bad |= (unsigned long long)__builtin_amdgcn_readfirstlane(*pubbad);  // (scalar: `bad` lives in an SGPR pair)
-            }
+            for (int s = 0; s < PanelSolve<NT, true, T>::NSTAGE; ++s) ps.stage(s, buf, kb, q, c, aop, bsym, bad);
             // B operand of the wave's columns: the old panel by symmetry; -I_4 on the pivot columns (their owner)
             T bop[NL];
             bop[0] = w ? bsym[1] : bsym[0];
@@ -268,9 +246,7 @@ __global__ __launch_bounds__(128, 2) void matinv_spd_tile2_f64(BatchRef<const do
 {
     __shared__ __attribute__((aligned(16))) double panel2[2 * 128 * 4];  // double buffered [row][4 pivot columns]
     __shared__ __attribute__((aligned(16))) double tbuf2[2 * 16 * 17];   // one padded 16 x 16 transpose buffer per wave
-    __shared__ __attribute__((aligned(16))) double pub[2 * 8 * 64];      // the solved panel as the solver's lanes hold it: A and B operand
-    __shared__ int pubbad;
-    spd_tile2_body<GP>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel2, tbuf2, pub, &pubbad, gp);
+    spd_tile2_body<GP>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel2, tbuf2, gp);
 }
 
 }  // namespace matinv
