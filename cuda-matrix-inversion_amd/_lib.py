@@ -36,7 +36,7 @@ NATIVE_NAMES = [
     "matinv_abi_version", "matinv_release_cache", "matinv_batched_malloc", "matinv_batched_free", "matinv_memcpy_2d",
     "matinv_device_synchronize", "matinv_tile_stats", "matinv_queue_create", "matinv_queue_submit", "matinv_queue_submit_chunks", "matinv_queue_pending",
     "matinv_queue_bins", "matinv_queue_flush", "matinv_queue_destroy", "matinv_queue_last_error",
-    "matinv_set_gj_policy", "matinv_device_count", "matinv_inverse_batched_host_multi", "matinv_comm_unique_id",
+    "matinv_set_gj_policy", "matinv_device_count", "matinv_shard_range", "matinv_inverse_batched_host_multi", "matinv_comm_unique_id",
     "matinv_comm_init_rank", "matinv_comm_destroy", "matinv_allgather_shards", "matinv_allgather_local",
 ]
 GJ_NATURAL_FIRST, GJ_PIVOT, GJ_ADAPTIVE = 0, 1, 2
@@ -90,6 +90,8 @@ def lib() -> ctypes.CDLL:
     L.matinv_set_gj_policy.restype = ci
     L.matinv_set_gj_policy.argtypes = [ci]
     L.matinv_device_count.restype = ci
+    L.matinv_shard_range.restype = ci
+    L.matinv_shard_range.argtypes = [sz, ci, ci, ci, vp, vp]
     L.matinv_comm_unique_id.restype = ci
     L.matinv_comm_unique_id.argtypes = [vp]
     L.matinv_comm_init_rank.restype = ci

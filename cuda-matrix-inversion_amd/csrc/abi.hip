@@ -357,6 +357,18 @@ int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int
     return MATINV_OK;
 }
 
+// contiguous block partition of [0, batch): ceil(batch / nshards) per shard, rounded up to the per-wavefront packing factor of the
+// small-n kernels (8 matrices per wave for n <= 8, 4 for n <= 16) so that no wavefront straddles two shards; trailing shards may be
+// short or empty (shard.partition in Python)
+void shard_range(size_t batch, int nshards, int n, int g, size_t &lo, size_t &hi)
+{
+    const size_t mult = n <= 8 ? 8 : (n <= 16 ? 4 : 1);
+    size_t per = (batch + (size_t)nshards - 1) / (size_t)nshards;
+    per = (per + mult - 1) / mult * mult;
+    lo = std::min(batch, (size_t)g * per);
+    hi = std::min(batch, lo + per);
+}
+
 int gfx950_devices(std::vector<int> &devs)
 {
     int count = 0;
@@ -386,9 +398,6 @@ int inverse_host_multi(int algo, int n, const void *hA, void *hAinv, size_t batc
     if (rc) return rc;
     if (nshards <= 0) nshards = (int)devs.size();
     if (nshards > 1024) return fail(MATINV_ERR_ARG, "nshards %d: at most 1024", nshards);
-    const size_t mult = n <= 8 ? 8 : (n <= 16 ? 4 : 1);
-    size_t per = (batch + (size_t)nshards - 1) / (size_t)nshards;
-    per = (per + mult - 1) / mult * mult;
     const size_t mat = (size_t)n * n;
     int home = 0;
     (void)hipGetDevice(&home);
@@ -410,7 +419,8 @@ int inverse_host_multi(int algo, int n, const void *hA, void *hAinv, size_t batc
     std::vector<Result> res((size_t)nshards);
     std::vector<std::thread> workers;
     for (int g = 0; g < nshards; ++g) {
-        const size_t lo = std::min(batch, (size_t)g * per), hi = std::min(batch, lo + per);
+        size_t lo = 0, hi = 0;
+        shard_range(batch, nshards, n, g, lo, hi);
         if (hi == lo) continue;
         const int dev = devs[(size_t)g % devs.size()];
         workers.emplace_back([=, &res]() {
@@ -676,6 +686,13 @@ int matinv_set_gj_policy(int policy)
     if (policy != MATINV_GJ_NATURAL_FIRST && policy != MATINV_GJ_PIVOT && policy != MATINV_GJ_ADAPTIVE)
         return fail(MATINV_ERR_ARG, "unknown Gauss-Jordan policy %d", policy);
     return set_gj_policy(policy);
+}
+
+int matinv_shard_range(size_t batch, int nshards, int n, int g, size_t *lo, size_t *hi)
+{
+    if (nshards < 1 || g < 0 || g >= nshards || n < 1 || !lo || !hi) return fail(MATINV_ERR_ARG, "matinv_shard_range: bad argument");
+    shard_range(batch, nshards, n, g, *lo, *hi);
+    return MATINV_OK;
 }
 
 int matinv_device_count(void)

@@ -139,6 +139,8 @@ int matinv_inverse_batched_host(int algo, int dtype, int n, const void *hA, void
 int matinv_inverse_batched_host_multi(int algo, int dtype, int n, const void *hA, void *hAinv, size_t batch, int *info,
                                       int nshards);
 int matinv_device_count(void); /* visible gfx950 devices, or a negative status */
+/* The block of shard g of nshards: [*lo, *hi) (pure host arithmetic, no device needed; the same partition as shard.py). */
+int matinv_shard_range(size_t batch, int nshards, int n, int g, size_t *lo, size_t *hi);
 
 /* Reassembly of device-resident shards over RCCL (librccl is opened at the first call: no link-time dependency). Every rank
  * contributes `count` elements (pad the short tail shard) and receives nranks * count.

@@ -56,3 +56,23 @@ def test_world2_gloo_shard_and_gather(n, batch):
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_c_partition_equals_the_python_one():
+    """matinv_shard_range (what matinv_inverse_batched_host_multi cuts the batch with) against shard.partition: pure host
+    arithmetic, no device needed."""
+    import ctypes
+    import importlib
+    lib = importlib.import_module("cuda-matrix-inversion_amd._lib")
+    shard = importlib.import_module("cuda-matrix-inversion_amd.shard")
+    L = lib.lib()
+    for batch in (0, 1, 7, 1000, 1003, 100_000, 1_000_000):
+        for world in (1, 2, 3, 8):
+            for n in (4, 8, 12, 16, 17, 64, 200):
+                want = shard.partition(batch, world, shard.packing_multiple(n))
+                for g in range(world):
+                    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+                    assert L.matinv_shard_range(batch, world, n, g, ctypes.byref(lo), ctypes.byref(hi)) == 0
+                    assert (lo.value, hi.value) == want[g], (batch, world, n, g)
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.matinv_shard_range(10, 2, 8, 2, ctypes.byref(lo), ctypes.byref(hi)) == lib.ERR_ARG
