@@ -37,7 +37,7 @@ NATIVE_NAMES = [
     "matinv_device_synchronize", "matinv_tile_stats", "matinv_queue_create", "matinv_queue_submit", "matinv_queue_submit_chunks", "matinv_queue_pending",
     "matinv_queue_bins", "matinv_queue_flush", "matinv_queue_destroy", "matinv_queue_last_error",
     "matinv_set_gj_policy", "matinv_device_count", "matinv_shard_range", "matinv_inverse_batched_host_multi", "matinv_comm_unique_id",
-    "matinv_comm_init_rank", "matinv_comm_destroy", "matinv_allgather_shards", "matinv_allgather_local",
+    "matinv_comm_init_rank", "matinv_comm_destroy", "matinv_allgather_shards", "matinv_allgather_local", "matinv_debug_rejects",
 ]
 GJ_NATURAL_FIRST, GJ_PIVOT, GJ_ADAPTIVE = 0, 1, 2
 
@@ -130,6 +130,8 @@ def lib() -> ctypes.CDLL:
     L.matinv_last_error.restype = ctypes.c_char_p
     L.matinv_abi_version.restype = ci
     L.matinv_release_cache.restype = ci
+    L.matinv_debug_rejects.restype = ctypes.c_longlong
+    L.matinv_debug_rejects.argtypes = [ci]
     for suffix in ("", "_f32"):
         for name in REFERENCE_GPU_NAMES + REFERENCE_DEVICE_NAMES:
             f = getattr(L, name + suffix)

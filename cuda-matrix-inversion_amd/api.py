@@ -114,6 +114,12 @@ def device_count() -> int:
     return k
 
 
+def debug_rejects(reset: bool = False) -> int:
+    """matinv_debug_rejects: matrices the first-pass kernels handed to a fallback since the last reset (needs
+    MATINV_DEBUG_REJECTS=1 in the environment before the library is loaded; otherwise 0)."""
+    return int(_lib.lib().matinv_debug_rejects(1 if reset else 0))
+
+
 def set_gj_policy(policy: int) -> int:
     """matinv_set_gj_policy (GJ_NATURAL_FIRST / GJ_PIVOT / GJ_ADAPTIVE); returns the previous policy."""
     old = _lib.lib().matinv_set_gj_policy(int(policy))

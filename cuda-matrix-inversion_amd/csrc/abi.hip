@@ -718,6 +718,7 @@ int matinv_release_cache(void)
     scratch_release_device();
     return MATINV_OK;
 }
+long long matinv_debug_rejects(int reset) { return debug_rejects(reset != 0); }
 const char *matinv_last_error(void) { return g_err; }
 
 // batchedCudaMalloc (/root/reference/src/helper.cu:103-118): ONE pitched device block, host table of row pointers.

@@ -284,7 +284,16 @@ hipError_t launch_gp_tile(int n, const T *As, const T *Bs, const T *Cs, const T 
 const char *name_gp_tile(bool f64, int n);
 // fused GP scalars on the SPD sweep of the Cholesky entry point (inverse in registers, folded, never stored): the sizes the
 // bordered form above no longer holds in one wavefront -- f64 80 < n <= 96, f32 96 < n <= 112 (tile_kernels.inc)
+// test hook (scratch.hip): MATINV_DEBUG_REJECTS=1 -> launchers with a work list add its final count to a running total
+hipError_t debug_note_rejects(const int *work_count, hipStream_t stream);
+long long debug_rejects(bool reset);
 bool gp_spd_tile_supports(bool f64, int n);
+int spd_onewave_max(bool f64);  // largest n of the one-wavefront symmetric sweep (fp64 112, fp32 160)
+// fp32 9 x 9 / 10 x 10 lower tiles on one wavefront (spd_wide_f32_kernels.hip, gp_spd_wide_f32_kernels.hip): the kernel launch only, ws = [count, list...]
+hipError_t enqueue_spd_tile_wide_f32(int n, BatchRef<const float> A, BatchRef<float> X, unsigned grid, unsigned b, int *info, int *ws,
+                                     hipStream_t stream);
+hipError_t enqueue_gp_spd_tile_wide_f32(int n, const float *As, const float *Bs, const float *Cs, const float *Ds, const float *Es, float *out,
+                                        unsigned grid, unsigned b, int *info, int *ws, hipStream_t stream);
 // two wavefronts per matrix, lower tiles only, fp64 112 < n <= 128: Cholesky entry point and fused pipeline (spd_tile2_kernels.hip);
 // MATINV_SPD_TILE2=0: off
 bool spd_tile2_supports(bool f64, int n);

@@ -469,7 +469,8 @@ hipError_t launch_chol_lds_worklist(int n, BatchRef<const T> A, BatchRef<T> X, c
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(matinv_chol_lds_worklist<T>, dim3(1024), dim3(LDS_THREADS), bytes, stream, A, X, info, n,
                        work_count, work_list);
-    return hipGetLastError();
+    e = hipGetLastError();
+    return e != hipSuccess ? e : debug_note_rejects(work_count, stream);
 }
 template <class T>
 hipError_t launch_chol_lds(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
@@ -507,7 +508,8 @@ hipError_t launch_gp_lds_worklist(int n, const T *As, const T *Bs, const T *Cs, 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(matinv_gp_lds_worklist<T>, dim3(1024), dim3(LDS_THREADS), bytes, stream, As, Bs, Cs, Ds, Es, out,
                        info, n, work_count, work_list);
-    return hipGetLastError();
+    e = hipGetLastError();
+    return e != hipSuccess ? e : debug_note_rejects(work_count, stream);
 }
 #define INST(T)                                                                                                        \
     template hipError_t launch_gj_lds<T>(int, BatchRef<const T>, BatchRef<T>, size_t, int *, hipStream_t);            \

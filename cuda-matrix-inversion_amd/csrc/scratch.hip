@@ -11,7 +11,10 @@
 // to a per-device list that any stream may draw from. matinv_release_cache() returns everything that is not in use.
 #include <stdio.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -154,5 +157,30 @@ void scratch_release_device()
     std::lock_guard<std::mutex> lock(g_mu);
     drop_free_blocks_locked(dev);
 }
+
+// ---- test hook: how many matrices did the first-pass kernels hand to their fallback? -----------------------------------------
+// A first-pass kernel that wrongly rejects everything is invisible in the results (the fallback computes them) and shows only as
+// a rate 10x below its neighbours (r03: the fp32 symmetric sweep of 9 x 9 tiles built with its accumulators in AGPRs did exactly
+// that). MATINV_DEBUG_REJECTS=1 makes every launcher that owns a work list read its count back (one stream synchronisation per
+// launch: a test mode, never a production one); matinv_debug_rejects() returns the running total.
+static std::atomic<long long> g_rejects{0};
+bool debug_rejects_on()
+{
+    static const bool on = []() {
+        const char *s = getenv("MATINV_DEBUG_REJECTS");
+        return s && *s && *s != '0';
+    }();
+    return on;
+}
+hipError_t debug_note_rejects(const int *work_count, hipStream_t stream)
+{
+    if (!debug_rejects_on() || !work_count) return hipSuccess;
+    int c = 0;
+    hipError_t e = hipMemcpyAsync(&c, work_count, sizeof c, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) g_rejects.fetch_add(c);
+    return e;
+}
+long long debug_rejects(bool reset) { return reset ? g_rejects.exchange(0) : g_rejects.load(); }
 
 }  // namespace matinv

@@ -431,6 +431,7 @@ static hipError_t launch_tilep4_worklist(int n, BatchRef<const T> A, BatchRef<T>
 {
     hipError_t e = enqueue_tilep4<T>(n, A, X, batch, info, stream, bad_count, bad_list, in_count, in_list, hint_out);
     if (e == hipSuccess) e = launch_gj_lds_worklist<T>(n, A, X, bad_count, bad_list, info, stream);
+    if (e == hipSuccess) e = debug_note_rejects(in_count, stream);
     return e;
 }
 

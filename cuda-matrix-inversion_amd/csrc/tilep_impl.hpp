@@ -509,6 +509,7 @@ static hipError_t launch_tilep_worklist(int n, BatchRef<const T> A, BatchRef<T> 
 {
     hipError_t e = enqueue_tilep<T>(n, A, X, batch, info, stream, in_count, in_list, hint_out, bad_count, bad_list);
     if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, bad_count, bad_list, info, stream);
+    if (e == hipSuccess) e = debug_note_rejects(in_count, stream);
     return e;
 }
 

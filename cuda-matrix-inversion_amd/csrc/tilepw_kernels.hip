@@ -16,8 +16,9 @@ template <>
 hipError_t launch_gj_tilepw_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
                                             const int *in_list, int *info, hipStream_t stream, hint_t *hint_out)
 {
-    if (tilep_variant() == 2) return launch_gj_tilepb<double>(n, A, X, batch, info, stream, in_count, in_list, hint_out);
-    return launch_tilepw<double>(n, A, X, batch, info, stream, in_count, in_list, hint_out);
+    hipError_t e = tilep_variant() == 2 ? launch_gj_tilepb<double>(n, A, X, batch, info, stream, in_count, in_list, hint_out)
+                                        : launch_tilepw<double>(n, A, X, batch, info, stream, in_count, in_list, hint_out);
+    return e != hipSuccess ? e : debug_note_rejects(in_count, stream);
 }
 
 const char *name_gj_tilepw(bool f64, int n)

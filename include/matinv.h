@@ -211,6 +211,13 @@ int matinv_abi_version(void);
  * Returns MATINV_OK, or MATINV_ERR_HIP / MATINV_ERR_NO_DEVICE. Never needed for correctness. */
 int matinv_release_cache(void);
 
+/* Test hook. With MATINV_DEBUG_REJECTS=1 in the environment when the library is loaded, every launcher whose first-pass kernel
+ * hands rejected matrices (needs row exchanges / not positive definite / singular) to a second kernel through a work list reads
+ * that list's length back after the launch (one stream synchronisation per launch: a test mode) and adds it to a running total.
+ * Returns the total; reset != 0 also zeroes it. Without the environment variable: always 0. The results never show whether
+ * the fast kernel or its fallback produced them -- the tests use this to pin "a well-conditioned batch is never rejected". */
+long long matinv_debug_rejects(int reset);
+
 #ifdef __cplusplus
 }
 #endif

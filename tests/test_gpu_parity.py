@@ -356,7 +356,8 @@ def test_large_n_global_family(n, batch):
 
 @pytest.mark.parametrize("forced", [False, True])
 @pytest.mark.parametrize("n,batch,dtype", [(129, 9, "f64"), (144, 6, "f64"), (177, 5, "f64"), (192, 5, "f64"), (200, 5, "f64"),
-                                           (333, 3, "f64"), (130, 7, "f32"), (200, 5, "f32"), (241, 4, "f32"), (256, 4, "f32"),
+                                           (333, 3, "f64"), (130, 7, "f32"), (144, 6, "f32"), (159, 5, "f32"), (160, 5, "f32"),
+                                           (161, 5, "f32"), (200, 5, "f32"), (241, 4, "f32"), (256, 4, "f32"),
                                            (512, 2, "f32"), (1000, 2, "f32")])
 def test_cholesky_large_n_blocked(n, batch, dtype, forced):
     """SPD inverse beyond the four-wave kernel: up to 12 x 12 (f64) / 16 x 16 (f32) tiles one wavefront per tile column
@@ -460,6 +461,48 @@ print("CHUNKED-OK")
     env = dict(os.environ, MATINV_BLOCKED_WS_MB="2")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CHUNKED-OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_first_pass_kernels_accept_every_well_conditioned_matrix():
+    """The fast kernels hand what they cannot finish (needs row exchanges, not positive definite) to a second kernel, so a fast
+    kernel that wrongly rejected EVERYTHING would still pass every parity test -- at a tenth of the speed (r03: a build of the fp32
+    symmetric sweep with 9 x 9 tiles did). MATINV_DEBUG_REJECTS=1 (matinv.h: matinv_debug_rejects) counts the hand-overs: zero for
+    diagonally dominant SPD batches through Gauss-Jordan, Cholesky and the fused pipeline at every size class and both precisions,
+    and non-zero for a general batch (the counter itself works). Child process: the switch is read once."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, importlib, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import spd_batch, general_batch
+api = importlib.import_module("cuda-matrix-inversion_amd.api")
+assert api.debug_rejects(reset=True) == 0
+batch = 37
+sizes = [3, 8, 16, 17, 24, 25, 31, 32, 40, 48, 63, 64, 65, 72, 80, 81, 96, 97, 100, 112, 113, 120, 128, 129, 144, 160, 161, 176, 192, 200, 256]
+for dt, code_ in ((np.float64, api.F64), (np.float32, api.F32)):
+    for n in sizes:
+        a = torch.from_numpy(spd_batch(n, batch, seed=n, dtype=dt)).cuda()
+        rng = np.random.default_rng(n)
+        v = [torch.from_numpy(rng.random(batch * n).astype(dt)).cuda() for _ in range(3)]
+        for what in ("gj", "chol", "mean"):
+            if what == "gj":
+                api.inverse_batched(a, n, api.ALGO_GAUSS_JORDAN, batch=batch)
+            elif what == "chol":
+                api.inverse_batched(a, n, api.ALGO_CHOLESKY, batch=batch)
+            else:
+                api.calcluateMean(n, v[0], a, v[1], v[2])
+            torch.cuda.synchronize()
+            r = api.debug_rejects(reset=True)
+            assert r == 0, (what, n, dt.__name__, r, api.kernel_name(api.ALGO_CHOLESKY if what != "gj" else api.ALGO_GAUSS_JORDAN, code_, n))
+g = torch.from_numpy(general_batch(64, 50, seed=1)).cuda()
+api.inverse_batched(g, 64, api.ALGO_GAUSS_JORDAN, batch=50)
+torch.cuda.synchronize()
+assert api.debug_rejects(reset=True) > 40
+print("REJECTS-OK")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MATINV_DEBUG_REJECTS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REJECTS-OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_large_n_singular_and_fp32():
@@ -764,7 +807,8 @@ def test_pipeline_fixtures(d, n, gold):
     assert np.abs(v - r["variances"]).mean() < 5e-5
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 7, 8, 9, 12, 16, 17, 33, 64, 65, 80, 81, 88, 96, 97, 100, 104, 112, 113, 127, 128, 129])
+@pytest.mark.parametrize("n", [1, 2, 5, 7, 8, 9, 12, 16, 17, 33, 64, 65, 80, 81, 88, 96, 97, 100, 104, 112, 113, 127, 128, 129,
+                               130, 144, 145, 159, 160, 161])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_pipeline_synthetic(n, dtype):
     rng = np.random.default_rng(n)
@@ -779,6 +823,26 @@ def test_pipeline_synthetic(n, dtype):
     v = api.calcluateVariance(n, t[0], t[1], t[2], t[4]).cpu().numpy().astype(np.float64)
     tol = 1e-10 if dtype == np.float64 else 2e-5
     assert np.abs(m - wm).max() < tol and np.abs(v - wv).max() < tol
+
+
+@pytest.mark.parametrize("n", [120, 130, 150, 160])
+def test_pipeline_not_spd_f32_wide_one_wave(n):
+    """fp32 fused pipeline on the one-wavefront symmetric sweep (8 x 8 .. 10 x 10 lower tiles, r03): an item whose matrix is not
+    positive definite goes to the LDS pipeline through the work list and comes back as info = failing column + NaN."""
+    batch = 9
+    rng = np.random.default_rng(n)
+    B = spd_batch(n, batch, seed=n).reshape(batch, n, n)
+    B[4, n - 3, n - 3] = -50.0 * n
+    a, c, d_ = (rng.random(batch * n) for _ in range(3))
+    t = [dev(x.astype(np.float32)) for x in (a, B.reshape(-1), c, d_)]
+    info = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
+    m = api.calcluateMean(n, t[0], t[1], t[2], t[3], info=info).cpu().numpy().astype(np.float64)
+    inf = info.cpu().numpy()
+    assert inf[4] == n - 2 and (np.delete(inf, 4) == 0).all()
+    assert np.isnan(m[4])
+    keep = lambda x, w: np.delete(x.reshape(batch, w), 4, 0).reshape(-1)
+    want = oracle.mean_batched(keep(a, n), keep(B, n * n), keep(c, n), keep(d_, n), n)
+    assert np.abs(np.delete(m, 4) - want).max() < 2e-5
 
 
 @pytest.mark.parametrize("n", [8, 13, 32, 72, 90, 100])
