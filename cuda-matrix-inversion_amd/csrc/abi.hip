@@ -814,11 +814,9 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     case MATINV_KERNEL_GLOBAL: return algo == MATINV_ALGO_CHOLESKY ? name_chol_global(f64) : name_gj_global(f64);
     case MATINV_KERNEL_BLOCKED:
         if (algo == MATINV_ALGO_GAUSS_JORDAN) {
-            // the kernel that dominates: the rank-128 MFMA update of the two-level scheme from n = 384 (128 x 128 workgroup
-            // tiles in fp32 when n rounded up to 128 wastes less than a fifth), the rank-32 VALU update below
-            if (n < 224) return f64 ? "matinv_bgj_update1<double>" : "matinv_bgj_update1<float>";
-            if (f64) return "matinv_bgj_update_mfma<double, false, 2>";
-            return ((n + 127) / 128) * 128 <= 1.2 * n ? "matinv_bgj_update_mfma<float, false, 4>" : "matinv_bgj_update_mfma<float, false, 2>";
+            // the kernel that dominates: the rank-128 MFMA update of the two-level scheme, the rank-32 VALU update below its threshold
+            if (n < blocked_gj_two_level_min()) return f64 ? "matinv_bgj_update1<double>" : "matinv_bgj_update1<float>";
+            return f64 ? "matinv_bgj_update_mfma<double, false, 2, 2>" : "matinv_bgj_update_mfma<float, false, 2, 2>";
         }
         return f64 ? "matinv_bgp_update<double>" : "matinv_bgp_update<float>";  // the trailing update: most of the time
     default: return "";

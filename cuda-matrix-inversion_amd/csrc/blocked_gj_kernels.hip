@@ -127,24 +127,29 @@ __global__ __launch_bounds__(1024) void matinv_bgj_panel1(const T *Win, T *Wout,
                 rs[k] = rs[p];
                 rs[p] = u;
             }
-            if (t == k || t == p) {
-                T *dst = xch + (t == p ? 0 : BGJ_PB);  // [0] = the pivot row (row p; also when p == k), [1] = old row k
+            // [0] = the pivot row (row p; also when p == k) ALREADY scaled by 1 / pivot, with the reciprocal itself in column j
+            // (r03: every thread used to scale it again, a third of the panel's multiplies); [1] = old row k
+            if (t == p) {
+                const T pvp = (T)1 / x[j];
 #pragma unroll
-                for (int c = 0; c < BGJ_PB; ++c) dst[c] = x[c];
+                for (int c = 0; c < BGJ_PB; ++c) xch[c] = (c == j) ? pvp : x[c] * pvp;
+            }
+            if (t == k && p != k) {
+#pragma unroll
+                for (int c = 0; c < BGJ_PB; ++c) xch[BGJ_PB + c] = x[c];
             }
             __syncthreads();
-            const T pv = (T)1 / xch[j];
             if (t == p && p != k) {
 #pragma unroll
                 for (int c = 0; c < BGJ_PB; ++c) x[c] = xch[BGJ_PB + c];
             }
             if (t == k) {
 #pragma unroll
-                for (int c = 0; c < BGJ_PB; ++c) x[c] = (c == j) ? pv : xch[c] * pv;
+                for (int c = 0; c < BGJ_PB; ++c) x[c] = xch[c];
             } else if (t < n) {
                 const T m = x[j];
 #pragma unroll
-                for (int c = 0; c < BGJ_PB; ++c) x[c] = (c == j) ? -m * pv : fma(-m, xch[c] * pv, x[c]);
+                for (int c = 0; c < BGJ_PB; ++c) x[c] = (c == j) ? -m * xch[j] : fma(-m, xch[c], x[c]);
             }
         }
     }
@@ -316,26 +321,28 @@ __global__ __launch_bounds__(1024) void matinv_bgj_panel(const T *Pin, size_t in
 // B operand of the block-level update: Bfull[k][col] = x_old[col][comp[K0 + k]] (the block's pivot rows as they stood when
 // the block started, in pivot order). 64 columns per workgroup through LDS: consecutive threads read consecutive k (comp is
 // the identity except for the swapped rows: nearly contiguous) and write consecutive columns.
+constexpr int BGJ_PRW = 32;  // columns per workgroup of matinv_bgj_pivot_rows: 33 KB of LDS in fp64 (64 columns = 66 KB left two
+                             // workgroups per CU and the kernel at 2.5 TB/s)
 template <class T>
-__global__ __launch_bounds__(256) void matinv_bgj_pivot_rows(const T *Win, T *Bfull, const int *comp, int n, int bw, int K0,
+__global__ __launch_bounds__(256) void matinv_bgj_pivot_rows(const T *Win, size_t in_stride, T *Bfull, const int *comp, int n, int bw, int K0,
                                                              const int *status)
 {
-    __shared__ T tile[64][BGJ_NB + 1];
+    __shared__ T tile[BGJ_PRW][BGJ_NB + 1];
     __shared__ int ksrc[BGJ_NB];
     const size_t item = blockIdx.y;
     if (status[item] != 0) return;
-    const int c0 = blockIdx.x * 64, t = threadIdx.x;
-    const T *win = Win + item * (size_t)n * n;
+    const int c0 = blockIdx.x * BGJ_PRW, t = threadIdx.x;
+    const T *win = Win + item * in_stride;
     T *bf = Bfull + item * (size_t)BGJ_NB * n;
     if (t < BGJ_NB) ksrc[t] = (t < bw) ? comp[item * (size_t)n + K0 + t] : 0;
     __syncthreads();
-    for (int e = t; e < 64 * BGJ_NB; e += 256) {
+    for (int e = t; e < BGJ_PRW * BGJ_NB; e += 256) {
         const int k = e % BGJ_NB, cc = e / BGJ_NB;
         if (k < bw && c0 + cc < n) tile[cc][k] = win[(size_t)(c0 + cc) * n + ksrc[k]];
     }
     __syncthreads();
-    for (int e = t; e < 64 * BGJ_NB; e += 256) {
-        const int cc = e % 64, k = e / 64;
+    for (int e = t; e < BGJ_PRW * BGJ_NB; e += 256) {
+        const int cc = e % BGJ_PRW, k = e / BGJ_PRW;
         if (k < bw && c0 + cc < n) bf[(size_t)k * n + c0 + cc] = tile[cc][k];
     }
 }
@@ -352,11 +359,23 @@ __global__ __launch_bounds__(256) void matinv_bgj_pivot_rows(const T *Win, T *Bf
 // then own 16 consecutive matrix rows of one column -- 128-byte segments for the gather of x_old and for the store. G and
 // the pivot rows (prepared k-major by matinv_bgj_panel / matinv_bgj_pivot_rows: gathering them here, per tile, from the
 // column-major x_old doubled the time of this kernel) go through LDS in slabs of 32.
-// MT = 16 x 16 MFMA tiles per wavefront and dimension: 2 -> 64 x 64 per workgroup (small n: fewer padded rows / columns),
-// 4 -> 128 x 128 (half the LDS reads and half the operand traffic per flop). The slabs are double-buffered through
+// MTC x MTR = 16 x 16 MFMA tiles per wavefront (columns x rows): 2 x 2 -> 64 x 64 per workgroup, the only one instantiated since
+// r03 (4 x 4 = 128 x 128 and 2 x 4 = 64 columns x 128 rows halve the operand traffic per flop and were slower: see below). The slabs are double-buffered through
 // registers: the next slab's global loads are in flight while the matrix cores work on the current one.
-template <class T, bool INNER, int MT>
-__global__ __launch_bounds__(256) void matinv_bgj_update_mfma(const T *Xold, size_t old_stride, T *Xnew, size_t new_stride,
+// Slab depth and occupancy (r03, measured on general fp64 input): the kernel is latency-bound -- each workgroup alternates between
+// waiting for a slab and 4 MFMAs per k-step, and only OTHER workgroups on the CU fill its gaps -- so thin slabs that leave room for
+// more workgroups win: 32-deep slabs / 3 waves per SIMD (130 VGPRs, 33 KB LDS) 2.60e5 inv/s at 256^2, 8.16e3 at 1024^2;
+// 16 / 5 (94 VGPRs): 3.17e5, 9.95e3; 8 / 6 (76 VGPRs, 8 KB): 3.26e5, 1.03e4; 8 / 8 (64 VGPRs, 40 B scratch): 3.00e5, 8.95e3.
+// A 64 x 128 workgroup tile (twice the flops per operand byte, 2 waves per SIMD) LOST 13 %. The fp32 128 x 128 tile: 16-deep slabs
+// 7.6e4 / 1.40e4 inv/s at 512^2 / 1024^2, 8-deep at 2..3 waves per SIMD 8.3e4 / 1.54e4.
+#ifndef MATINV_BGJ_KS
+#define MATINV_BGJ_KS 8
+#endif
+#ifndef MATINV_BGJ_OCC
+#define MATINV_BGJ_OCC 6
+#endif
+template <class T, bool INNER, int MTC, int MTR = MTC>
+__global__ __launch_bounds__(256, MTC * MTR <= 4 ? MATINV_BGJ_OCC : 2) void matinv_bgj_update_mfma(const T *Xold, size_t old_stride, T *Xnew, size_t new_stride,
                                                               const T *Gsrc, size_t g_stride, const T *Bsrc, size_t b_stride, int ldb,
                                                               const int *rmap, int n, int ncols, int kw, int Z0, int skip0,
                                                               const int *status, unsigned gx, unsigned gy, unsigned nb)
@@ -365,18 +384,19 @@ __global__ __launch_bounds__(256) void matinv_bgj_update_mfma(const T *Xold, siz
     if (!tile.valid) return;
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
-    constexpr int WT = 16 * MT, TS = 2 * WT;   // wave tile, workgroup tile
-    constexpr int KS = MT == 4 ? 16 : 32;      // slab depth
-    constexpr int PER = KS * TS / 256;         // slab elements per thread and operand
-    // fp32: row stride TS + 16, so that the four k-groups of an MFMA operand read (rows k .. k+3, 16 consecutive elements each)
-    // land in disjoint LDS banks (1024^2 x 256: 19.6 -> 18.5 ms). fp64 keeps stride TS: the padded slabs (41 KB) cost a
+    // wave tile: 16 MTC columns x 16 MTR rows; workgroup tile (2 x 2 waves): TSC columns x TSR rows
+    constexpr int WTC = 16 * MTC, WTR = 16 * MTR, TSC = 2 * WTC, TSR = 2 * WTR;
+    constexpr int KS = MATINV_BGJ_KS;  // slab depth
+    constexpr int PERG = KS * TSR / 256, PERB = KS * TSC / 256;  // slab elements per thread: G (rows), pivot rows (columns)
+    // fp32: row stride + 16, so that the four k-groups of an MFMA operand read (rows k .. k+3, 16 consecutive elements each)
+    // land in disjoint LDS banks (1024^2 x 256: 19.6 -> 18.5 ms). fp64 keeps the plain stride: the padded slabs (41 KB) cost a
     // workgroup per CU, which outweighs the conflicts there (31.3 ms unpadded, 31.8 padded).
-    constexpr int LDS_ROW = TS + (sizeof(T) == 8 ? 0 : 16);
-    __shared__ T Gt[KS][LDS_ROW], Bt[KS][LDS_ROW];
-    __shared__ int rsrc[TS];
+    constexpr int PAD = sizeof(T) == 8 ? 0 : 16;
+    __shared__ T Gt[KS][TSR + PAD], Bt[KS][TSC + PAD];
+    __shared__ int rsrc[TSR];
     const size_t item = tile.z;
     if (status[item] != 0) return;
-    const int j0 = tile.x * TS, i0 = tile.y * TS;  // first column / row of the tile
+    const int j0 = tile.x * TSC, i0 = tile.y * TSR;  // first column / row of the tile
     const T *xold = Xold + item * old_stride;
     T *xnew = Xnew + item * new_stride;
     const T *g = Gsrc + item * g_stride;
@@ -384,73 +404,103 @@ __global__ __launch_bounds__(256) void matinv_bgj_update_mfma(const T *Xold, siz
     const int *rm = rmap + item * (size_t)n;
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int q = l >> 4, c = l & 15;
-    const int wc = (wv & 1) * WT, wr = (wv >> 1) * WT;  // this wave's columns x rows inside the tile
-    if (t < TS) rsrc[t] = (i0 + t < n) ? rm[i0 + t] : 0;
+    const int wc = (wv & 1) * WTC, wr = (wv >> 1) * WTR;  // this wave's columns x rows inside the tile
+    if (t < TSR) rsrc[t] = (i0 + t < n) ? rm[i0 + t] : 0;
     // tiles whose columns all belong to the skipped range only copy (block level) or have nothing to do (inner)
-    const bool all_skipped = j0 >= skip0 && j0 + TS <= skip0 + kw;
+    const bool all_skipped = j0 >= skip0 && j0 + TSC <= skip0 + kw;
     if (INNER && all_skipped) return;
-    vec4 acc[MT][MT] = {};
+    vec4 acc[MTC][MTR] = {};
     if (!all_skipped) {
-        T gq[PER], bq[PER];
+        T gq[PERG], bq[PERB];
+        // Slab element i of thread t is (k = t / TS + i * 256 / TS, r = t % TS): the row / column r is the same for every i, so the
+        // addresses are one base pointer + multiples of a stride and the edge tests are hoisted (r03: the kernel issued 9.3 vector-ALU
+        // instructions per MFMA, nearly all of them 64-bit address arithmetic and predicates, PMC on 1024^2). Only a ragged LAST slab
+        // (kw not a multiple of KS) clamps k.
+        constexpr int KRG = 256 / TSR, KRB = 256 / TSC;
+        const int rG = t % TSR, kG = t / TSR, rB = t % TSC, kB = t / TSC;
+        const bool g_in = i0 + rG < n, b_in = j0 + rB < ncols;
+        const T *gcol = g + (g_in ? i0 + rG : n - 1);
+        const T *bcol = bsrc + (b_in ? j0 + rB : ncols - 1);
+        const size_t gstep = (size_t)KRG * n, bstep = (size_t)KRB * ldb;
         // The prefetch is RAW (addresses clamped into the operands, so the loads are unconditional); padding is zeroed when
         // the slab is staged. Written as `in ? load : 0` the select sits right behind the loads and the wave waits for them
         // before the MFMAs they are meant to hide behind (the same change made the blocked Cholesky update 1.3 x faster).
         auto fetch = [&](int ks) {
+            if (ks + KS <= kw) {  // block-uniform
+                const T *gp = gcol + (size_t)(ks + kG) * n;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int e = t + 256 * i, k = e / TS, r = e % TS;
-                const int kc = (ks + k < kw) ? ks + k : kw - 1;
-                gq[i] = g[(size_t)kc * n + ((i0 + r < n) ? i0 + r : n - 1)];
-                bq[i] = bsrc[(size_t)kc * ldb + ((j0 + r < ncols) ? j0 + r : ncols - 1)];
+                for (int i = 0; i < PERG; ++i, gp += gstep) gq[i] = *gp;
+                const T *bp = bcol + (size_t)(ks + kB) * ldb;
+#pragma unroll
+                for (int i = 0; i < PERB; ++i, bp += bstep) bq[i] = *bp;
+            } else {
+#pragma unroll
+                for (int i = 0; i < PERG; ++i) {
+                    const int k = ks + kG + i * KRG;
+                    gq[i] = gcol[(size_t)(k < kw ? k : kw - 1) * n];
+                }
+#pragma unroll
+                for (int i = 0; i < PERB; ++i) {
+                    const int k = ks + kB + i * KRB;
+                    bq[i] = bcol[(size_t)(k < kw ? k : kw - 1) * ldb];
+                }
             }
         };
         fetch(0);
         for (int ks = 0; ks < kw; ks += KS) {
             __syncthreads();  // the previous slab has been consumed (and rsrc is visible after the first one)
+            const int kleft = kw - ks;  // >= KS except in a ragged last slab
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int e = t + 256 * i, k = e / TS, r = e % TS;
-                Gt[k][r] = (ks + k < kw && i0 + r < n) ? gq[i] : (T)0;
-                Bt[k][r] = (ks + k < kw && j0 + r < ncols) ? bq[i] : (T)0;
-            }
+            for (int i = 0; i < PERG; ++i) Gt[kG + i * KRG][rG] = (g_in && kG + i * KRG < kleft) ? gq[i] : (T)0;
+#pragma unroll
+            for (int i = 0; i < PERB; ++i) Bt[kB + i * KRB][rB] = (b_in && kB + i * KRB < kleft) ? bq[i] : (T)0;
             __syncthreads();
             if (ks + KS < kw) fetch(ks + KS);
 #pragma unroll
             for (int kk = 0; kk < KS / 4; ++kk) {
-                T a[MT], b[MT];
+                T a[MTC], b[MTR];
 #pragma unroll
-                for (int u = 0; u < MT; ++u) {
-                    a[u] = Bt[4 * kk + q][wc + 16 * u + c];  // MFMA rows  <-> matrix columns
-                    b[u] = Gt[4 * kk + q][wr + 16 * u + c];  // MFMA columns <-> matrix rows
-                }
+                for (int u = 0; u < MTC; ++u) a[u] = Bt[4 * kk + q][wc + 16 * u + c];  // MFMA rows  <-> matrix columns
 #pragma unroll
-                for (int u = 0; u < MT; ++u)
+                for (int v = 0; v < MTR; ++v) b[v] = Gt[4 * kk + q][wr + 16 * v + c];  // MFMA columns <-> matrix rows
 #pragma unroll
-                    for (int v = 0; v < MT; ++v) acc[u][v] = G::mfma(a[u], b[v], acc[u][v]);
+                for (int u = 0; u < MTC; ++u)
+#pragma unroll
+                    for (int v = 0; v < MTR; ++v) acc[u][v] = G::mfma(a[u], b[v], acc[u][v]);
             }
         }
     } else {
         __syncthreads();
     }
+    // epilogue: lane (q, c) owns rows i0 + wr + 16 v + c of columns j0 + wc + 16 u + trow(r, q); per column one base offset
+    int rs_[MTR];
+    bool zr[MTR];
 #pragma unroll
-    for (int u = 0; u < MT; ++u)
+    for (int v = 0; v < MTR; ++v) {
+        const int lrow = wr + 16 * v + c, row = i0 + lrow;
+        rs_[v] = rsrc[lrow];
+        zr[v] = row >= Z0 && row < Z0 + kw;
+    }
+    const int row0 = i0 + wr + c;
+#pragma unroll
+    for (int u = 0; u < MTC; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = j0 + wc + 16 * u + G::trow(r, q);
             if (col >= ncols) continue;
             const bool skipped = col >= skip0 && col < skip0 + kw;
             if (INNER && skipped) continue;
+            const size_t cb = (size_t)col * n;
+            const T *xo = xold + cb;
+            T *xn = xnew + cb + row0;
+            const T *gc = g + (size_t)(skipped ? col - skip0 : 0) * n + row0;
 #pragma unroll
-            for (int v = 0; v < MT; ++v) {
-                const int lrow = wr + 16 * v + c, row = i0 + lrow;
-                if (row >= n) continue;
+            for (int v = 0; v < MTR; ++v) {
+                if (row0 + 16 * v >= n) continue;
                 T out;
-                if (skipped) out = g[(size_t)(col - skip0) * n + row];  // the finished block columns
-                else {
-                    const T old = (row >= Z0 && row < Z0 + kw) ? (T)0 : xold[(size_t)col * n + rsrc[lrow]];
-                    out = old + acc[u][v][r];
-                }
-                xnew[(size_t)col * n + row] = out;
+                if (skipped) out = gc[16 * v];  // the finished block columns
+                else out = (zr[v] ? (T)0 : xo[rs_[v]]) + acc[u][v][r];
+                xn[16 * v] = out;
             }
         }
 }
@@ -502,6 +552,20 @@ size_t blocked_workspace_cap()
 
 bool blocked_gj_supports(int n) { return n >= 1 && n <= 1024; }
 
+// smallest n that takes the two-level scheme (MFMA updates); below it: one level, rank-32 vector-ALU updates. MATINV_BGJ_TWO_LEVEL_MIN
+// overrides (A/B switch). r02: 384. r03: 224 at first (general input, f64: 256^2 2.25e5 -> 2.55e5 inv/s, 320^2 1.18e5 -> 1.49e5; f32
+// 320^2 1.80e5 -> 2.00e5; 200^2 equal), then 160 once the MFMA update ran at six waves per SIMD: 193^2 / 200^2 / 216^2
+// 3.25e5 / 3.15e5 / 2.88e5 -> 4.11e5 / 4.15e5 / 3.83e5
+int blocked_gj_two_level_min()
+{
+    static const int v = []() {
+        const char *s = getenv("MATINV_BGJ_TWO_LEVEL_MIN");
+        const int e = s && *s ? atoi(s) : 0;
+        return e > 0 ? e : 160;
+    }();
+    return v;
+}
+
 template <class T>
 static hipError_t launch_gj_blocked_small(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
@@ -543,14 +607,7 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
 {
     if (!blocked_gj_supports(n)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    // MATINV_BGJ_TWO_LEVEL_MIN: smallest n that takes the two-level scheme (A/B switch). Default 224 since r03 (was 384):
-    // measured on general input, f64: 256^2 2.25e5 -> 2.55e5 inv/s, 320^2 1.18e5 -> 1.49e5; f32 320^2 1.80e5 -> 2.00e5; 200^2 equal
-    static const int two_level_min = []() {
-        const char *s = getenv("MATINV_BGJ_TWO_LEVEL_MIN");
-        const int v = s && *s ? atoi(s) : 0;
-        return v > 0 ? v : 224;
-    }();
-    if (n < two_level_min) return launch_gj_blocked_small<T>(n, A, X, batch, info, stream);
+    if (n < blocked_gj_two_level_min()) return launch_gj_blocked_small<T>(n, A, X, batch, info, stream);
     // per item: two working copies, two block buffers (n x NB), the block's pivot rows (NB x n), a sub-panel's b strip
     const size_t per_item = (2 * (size_t)n * n + 3 * (size_t)BGJ_NB * n + (size_t)BGJ_PB * BGJ_NB) * sizeof(T);
     size_t chunk = blocked_workspace_cap() / per_item;  // bounded workspace, grid.y / grid.z limit
@@ -569,20 +626,37 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
     int *rowsrc = iws, *comp0 = rowsrc + chunk * (size_t)n, *comp1 = comp0 + chunk * (size_t)n, *pivots = comp1 + chunk * (size_t)n,
         *status = pivots + chunk * (size_t)n;
     const unsigned threads = (unsigned)((n + 63) / 64 * 64);
-    const unsigned g = (unsigned)((n + BGJ_TILE - 1) / BGJ_TILE), g128 = (unsigned)((n + 127) / 128);
-    // 128 x 128 workgroup tiles: fp32 only (in fp64 their 128 accumulator registers leave one wave per SIMD: 4.9e3 inv/s at
-    // n = 1024 against 6.6e3 with 64 x 64 tiles), and only once the padding they bring (n rounded up to 128) is below a fifth
-    const bool big = sizeof(T) == 4 && (double)(g128 * 128) <= 1.2 * n;
-    const int nbw = BGJ_NB;
+    const unsigned g = (unsigned)((n + BGJ_TILE - 1) / BGJ_TILE);
+    // (128 x 128 workgroup tiles were used for fp32 until r03; with 8-deep slabs the 64 x 64 tile at six waves per SIMD is faster
+    // there too: 1.65e4 against 1.54e4 inv/s at 1024^2, 8.9e4 against 8.3e4 at 512^2)
+    // columns per block (a multiple of the sub-panel width, <= BGJ_NB): MATINV_BGJ_NB overrides (A/B switch)
+    static const int nb_env = []() {
+        const char *s = getenv("MATINV_BGJ_NB");
+        const int v = s && *s ? atoi(s) : 0;
+        return (v >= BGJ_PB && v <= BGJ_NB && v % BGJ_PB == 0) ? v : 0;
+    }();
+    const int nbw = nb_env ? nb_env : BGJ_NB;
     for (size_t first = 0; first < batch; first += chunk) {
         const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
-        hipLaunchKernelGGL(matinv_bgj_init<T>, dim3(64, b), dim3(256), 0, stream, A, first, W0, n, status);
-        T *cur = W0, *nxt = W1;
+        // A flat batch (one matrix after the other, the usual case) is read in place by the first block's kernels; only a pointer
+        // table needs the gathering copy (r03: the copy was 6 % of the time at 256^2)
+        const T *cur;
+        size_t cur_stride = nn;
+        T *nxt = W1;
+        if (!A.table && A.stride >= nn) {
+            cur = A.base + first * A.stride;
+            cur_stride = A.stride;
+            hipError_t em = hipMemsetAsync(status, 0, b * sizeof(int), stream);
+            if (em != hipSuccess) { (void)scratch_free(ws, stream); (void)scratch_free(iws, stream); return em; }
+        } else {
+            hipLaunchKernelGGL(matinv_bgj_init<T>, dim3(64, b), dim3(256), 0, stream, A, first, W0, n, status);
+            cur = W0;
+        }
         for (int K0 = 0; K0 < n; K0 += nbw) {
             const int bw = n - K0 < nbw ? n - K0 : nbw;
             // the block's sub-panels, inside the block buffers: X0 = the block columns of cur, then P0, P1, P0, ...
             const T *pin = cur + (size_t)K0 * n;
-            size_t in_stride = nn;
+            size_t in_stride = cur_stride;
             T *pout = P0;
             const int *cprev = nullptr;
             int *cnext = comp0;
@@ -591,14 +665,9 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
                 hipLaunchKernelGGL(matinv_bgj_panel<T>, dim3(b), dim3(threads), 0, stream, pin, in_stride, pout, blk, Bin, rowsrc, cprev,
                                    cnext, pivots, n, bw, c0, K0, status);
                 if (bw > pb) {
-                    if (big)
-                        hipLaunchKernelGGL((matinv_bgj_update_mfma<T, true, 4>), dim3(xcd_tile_grid((bw + 127) / 128, g128, b)), dim3(256), 0, stream, pin,
-                                           in_stride, pout, blk, pout + (size_t)c0 * n, blk, Bin, strip, BGJ_NB, rowsrc, n, bw, pb, K0 + c0,
-                                           c0, status, (unsigned)((bw + 127) / 128), g128, b);
-                    else
-                        hipLaunchKernelGGL((matinv_bgj_update_mfma<T, true, 2>), dim3(xcd_tile_grid((bw + 63) / 64, g, b)), dim3(256), 0, stream, pin,
-                                           in_stride, pout, blk, pout + (size_t)c0 * n, blk, Bin, strip, BGJ_NB, rowsrc, n, bw, pb, K0 + c0,
-                                           c0, status, (unsigned)((bw + 63) / 64), g, b);
+                    hipLaunchKernelGGL((matinv_bgj_update_mfma<T, true, 2>), dim3(xcd_tile_grid((bw + 63) / 64, g, b)), dim3(256), 0, stream, pin,
+                                       in_stride, pout, blk, pout + (size_t)c0 * n, blk, Bin, strip, BGJ_NB, rowsrc, n, bw, pb, K0 + c0,
+                                       c0, status, (unsigned)((bw + 63) / 64), g, b);
                 }
                 pin = pout, in_stride = blk;
                 pout = (pout == P0) ? P1 : P0;
@@ -607,17 +676,13 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
             }
             // pin = the finished block columns G, cprev = the block's composite row map
             if (bw < n)
-                hipLaunchKernelGGL(matinv_bgj_pivot_rows<T>, dim3((n + 63) / 64, b), dim3(256), 0, stream, cur, Bfull, cprev, n, bw, K0,
-                                   status);
-            if (big)
-                hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 4>), dim3(xcd_tile_grid(g128, g128, b)), dim3(256), 0, stream, cur, nn, nxt, nn, pin,
-                                   blk, Bfull, blk, n, cprev, n, n, bw, K0, K0, status, g128, g128, b);
-            else
-                hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 2>), dim3(xcd_tile_grid(g, g, b)), dim3(256), 0, stream, cur, nn, nxt, nn, pin, blk,
-                                   Bfull, blk, n, cprev, n, n, bw, K0, K0, status, g, g, b);
-            T *tmp = cur;
+                hipLaunchKernelGGL(matinv_bgj_pivot_rows<T>, dim3((n + BGJ_PRW - 1) / BGJ_PRW, b), dim3(256), 0, stream, cur, cur_stride, Bfull,
+                                   cprev, n, bw, K0, status);
+            hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 2>), dim3(xcd_tile_grid(g, g, b)), dim3(256), 0, stream, cur, cur_stride, nxt, nn, pin,
+                               blk, Bfull, blk, n, cprev, n, n, bw, K0, K0, status, g, g, b);
             cur = nxt;
-            nxt = tmp;
+            cur_stride = nn;
+            nxt = (nxt == W1) ? W0 : W1;
         }
         hipLaunchKernelGGL(matinv_bgj_finish<T>, dim3(g, b), dim3(256), 0, stream, cur, X, first, pivots, info, n, status);
     }

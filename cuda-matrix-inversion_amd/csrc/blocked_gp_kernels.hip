@@ -25,7 +25,12 @@
 namespace matinv {
 
 constexpr int BGP_PB = 64;     // panel width
-constexpr int BGP_KS = 16;     // k-slab of the update kernel (LDS staging depth)
+constexpr int BGP_KS = SLAB_KS;  // k-slab of the update kernel (LDS staging depth)
+// waves per SIMD the two MFMA product kernels are built for (r03): 5 (<= 102 registers) against the 4 hipcc chose by itself:
+// SPD inverse fp64 1024^2 2.15e4 -> 2.43e4 inv/s, 256^2 5.6e5 -> 6.2e5; 8-deep slabs at 6 waves: 2.48e4 / 6.1e5 (fp32 slightly slower)
+#ifndef MATINV_BGP_OCC
+#define MATINV_BGP_OCC 5
+#endif
 constexpr int BGP_TILE = 64;   // update tile edge
 constexpr int BGP_THREADS = 256;
 constexpr int BGP_LDS = SLAB_LDS;  // row stride of the LDS slabs [k][row] (slab_mma.hpp)
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_panel(T *W, int n, int
 // trailing update: W[I, J] -= L[I, K] L[J, K]^T for 64 x 64 tiles with jbeg <= J < jend, I >= J (rows up to row_end - 1);
 // K = the kcnt panel columns from kbeg on (one panel of 64, or the two panels of a pair: see launch_gp_blocked)
 template <class T>
-__global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_update(T *W, int n, int ld, int row_end, int kbeg, int kcnt, int jbeg,
+__global__ __launch_bounds__(BGP_THREADS, MATINV_BGP_OCC) void matinv_bgp_update(T *W, int n, int ld, int row_end, int kbeg, int kcnt, int jbeg,
                                                                  int jend, const int *status, unsigned gx, unsigned gy, unsigned nb)
 {
     const XcdTile tile = xcd_tile_of(blockIdx.x, gx, gy, nb);
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_binv_init(BatchRef<const T
 
 // X[i][j] = sum_{c >= max(i,j)} Y[i][c] Y[j][c]; one workgroup per 64 x 64 tile with j0 <= i0, mirrored on write
 template <class T>
-__global__ __launch_bounds__(BGP_THREADS) void matinv_binv_syrk(const T *W, BatchRef<T> Xout, size_t first, int *info, int n,
+__global__ __launch_bounds__(BGP_THREADS, MATINV_BGP_OCC) void matinv_binv_syrk(const T *W, BatchRef<T> Xout, size_t first, int *info, int n,
                                                                 int ld, const int *status, unsigned g, unsigned nb)
 {
     const XcdTile tile = xcd_tile_of(blockIdx.x, g, g, nb);

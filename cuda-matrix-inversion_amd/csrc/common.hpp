@@ -128,6 +128,7 @@ bool onewave_wide();  // r03: one-wavefront kernels on VGPRs + AGPRs beyond 256 
 
 // blocked Gauss-Jordan with partial pivoting for large general matrices (blocked_gj_kernels.hip)
 bool blocked_gj_supports(int n);
+int blocked_gj_two_level_min();
 size_t blocked_workspace_cap();  // bytes; MATINV_BLOCKED_WS_MB overrides the 16 GiB default
 template <class T>
 hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);

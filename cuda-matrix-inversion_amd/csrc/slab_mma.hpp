@@ -5,7 +5,10 @@
 
 namespace matinv {
 
-constexpr int SLAB_KS = 16;   // columns per slab
+#ifndef MATINV_SLAB_KS
+#define MATINV_SLAB_KS 16
+#endif
+constexpr int SLAB_KS = MATINV_SLAB_KS;   // columns per slab
 constexpr int SLAB_LDS = 80;  // row stride of a slab S[k][row] in LDS: the four k-groups of an MFMA operand read land in disjoint banks
 
 // One slab (SLAB_KS columns, staged in LDS as S[k][row]) of the 64 x 64 tile product D[J, I] += sum_k Sj[k][J] Si[k][I] on the matrix
