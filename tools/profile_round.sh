@@ -25,8 +25,8 @@ for w in gj64 gj16 gj24 gj32 chol64 gj128 gj64g gj32g gj128g; do
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $W -o gj64_SQ1 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-others > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE -d $W -o gj64_SQ2 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-others > /dev/null 2>&1
-for w in gj64g gj128g chol1024; do
-B=""; [ $w = chol1024 ] && B="--batch 256"
+for w in gj64g gj128g chol1024 gj1024g gj256g; do
+B=""; [ $w = chol1024 ] && B="--batch 256"; [ $w = gj1024g ] && B="--batch 256"; [ $w = gj256g ] && B="--batch 3000"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $W -o ${w}_SQ1 -- python3 $R/bench.py --workload $w $B --steps 3 --warmup 2 --no-cpu-baseline --no-others > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_SALU -d $W -o ${w}_SQ2 -- python3 $R/bench.py --workload $w $B --steps 3 --warmup 2 --no-cpu-baseline --no-others > /dev/null 2>&1
 done

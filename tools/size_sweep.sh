@@ -7,6 +7,6 @@ echo "# size sweep: python tools/time_sizes.py <dtype> <algo> n...   (kernel-onl
 for dt in f64 f32; do for algo in gj chol; do echo "## inversion $dt $algo"; python3 $R/tools/time_sizes.py $dt $algo $S 2>/dev/null | grep "n="; done; done
 for dt in f64 f32; do
   echo "## inversion $dt gj, GENERAL U(0,1) input (needs row exchanges)"
-  MATINV_TIME_GENERAL=1 python3 $R/tools/time_sizes.py $dt gj 8 16 20 32 40 48 50 64 72 80 96 100 128 130 160 192 200 256 512 1024 2>/dev/null | grep "n="
+  MATINV_TIME_GENERAL=1 python3 $R/tools/time_sizes.py $dt gj 8 16 20 32 40 48 50 64 72 80 96 100 128 130 160 192 200 224 256 384 512 768 1024 2>/dev/null | grep "n="
 done
 for dt in f64 f32; do echo "## fused mean pipeline $dt"; python3 $R/tools/time_gp_sizes.py $dt $S 2>/dev/null | grep "n="; done
