@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void matinv_bgj_pivot_rows(const T *Win, size_
 // waiting for a slab and 4 MFMAs per k-step, and only OTHER workgroups on the CU fill its gaps -- so thin slabs that leave room for
 // more workgroups win: 32-deep slabs / 3 waves per SIMD (130 VGPRs, 33 KB LDS) 2.60e5 inv/s at 256^2, 8.16e3 at 1024^2;
 // 16 / 5 (94 VGPRs): 3.17e5, 9.95e3; 8 / 6 (76 VGPRs, 8 KB): 3.26e5, 1.03e4; 8 / 8 (64 VGPRs, 40 B scratch): 3.00e5, 8.95e3.
-// A 64 x 128 workgroup tile (twice the flops per operand byte, 2 waves per SIMD) LOST 13 %. The fp32 128 x 128 tile: 16-deep slabs
+// A 64 x 128 workgroup tile (twice the flops per operand byte, 2 waves per SIMD) LOST 13 %. Two / three slabs in flight instead of one
+// (rotating register slots, 80 / 96 VGPRs): 1024^2 1.08e4 -> 8.3e3 / 8.0e3, 256^2 3.5e5 -> 2.9e5 / 2.8e5 -- also lost. The fp32 128 x 128 tile: 16-deep slabs
 // 7.6e4 / 1.40e4 inv/s at 512^2 / 1024^2, 8-deep at 2..3 waves per SIMD 8.3e4 / 1.54e4.
 #ifndef MATINV_BGJ_KS
 #define MATINV_BGJ_KS 8
