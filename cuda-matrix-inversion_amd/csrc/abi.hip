@@ -555,10 +555,11 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
             return MATINV_OK;
         }
     }
-    // One wavefront per tile column up to n = 176: beyond it the blocked path (matrix-core tile products since late r02) is the
-    // faster one -- fp64 192^2: 1.42e6 items/s here, 1.56e6 blocked; fp32 2.65e6 / 2.92e6; at 160^2 this kernel still leads
-    // (2.2e6 / 1.9e6). (The kernel itself serves n <= 192 / 208: tile4_impl.hpp, gp_tile4_wide_supports.)
-    if (tile4_supports(n) || (n > 128 && n <= 176)) {
+    // One wavefront per tile column up to n = 160: beyond it the blocked path (matrix-core tile products since late r02, five waves
+    // per SIMD since r03) is the faster one -- fp64 176^2: 1.73e6 items/s here, 1.93e6 blocked; fp32 161^2 / 176^2: 3.34e6 / 3.12e6 here,
+    // 3.85e6 / 3.59e6 blocked; at 160^2 fp64 this kernel still leads (2.20e6 / 2.06e6). (The kernel itself serves n <= 192 / 208:
+    // tile4_impl.hpp, gp_tile4_wide_supports.)
+    if (tile4_supports(n) || (n > 128 && n <= 160)) {
         static const bool use_tile4 = []() {
             const char *s = getenv("MATINV_GP_TILE4");  // A/B switch for profiling; default on
             return !(s && *s == '0');
