@@ -293,6 +293,11 @@ int spd_onewave_max(bool f64);  // largest n of the one-wavefront symmetric swee
 // fp32 9 x 9 / 10 x 10 lower tiles on one wavefront (spd_wide_f32_kernels.hip, gp_spd_wide_f32_kernels.hip): the kernel launch only, ws = [count, list...]
 hipError_t enqueue_spd_tile_wide_f32(int n, BatchRef<const float> A, BatchRef<float> X, unsigned grid, unsigned b, int *info, int *ws,
                                      hipStream_t stream);
+// fp64 7 x 7 lower tiles on one wavefront (spd_wide_f64_kernels.hip, compiled with VGPR-form MFMAs)
+hipError_t enqueue_spd_tile_wide_f64(int n, BatchRef<const double> A, BatchRef<double> X, unsigned grid, unsigned b, int *info, int *ws,
+                                     hipStream_t stream);
+hipError_t enqueue_gp_spd_tile_wide_f64(int n, const double *As, const double *Bs, const double *Cs, const double *Ds, const double *Es,
+                                        double *out, unsigned grid, unsigned b, int *info, int *ws, hipStream_t stream);
 hipError_t enqueue_gp_spd_tile_wide_f32(int n, const float *As, const float *Bs, const float *Cs, const float *Ds, const float *Es, float *out,
                                         unsigned grid, unsigned b, int *info, int *ws, hipStream_t stream);
 // two wavefronts per matrix, lower tiles only, fp64 112 < n <= 128: Cholesky entry point and fused pipeline (spd_tile2_kernels.hip);
