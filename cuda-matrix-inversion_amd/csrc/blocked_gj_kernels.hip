@@ -379,8 +379,11 @@ template <class T, bool INNER, int MTC, int MTR = MTC>
 __global__ __launch_bounds__(256, MTC * MTR <= 4 ? MATINV_BGJ_OCC : 2) void matinv_bgj_update_mfma(const T *Xold, size_t old_stride, T *Xnew, size_t new_stride,
                                                               const T *Gsrc, size_t g_stride, const T *Bsrc, size_t b_stride, int ldb,
                                                               const int *rmap, int n, int ncols, int kw, int Z0, int skip0,
-                                                              const int *status, unsigned gx, unsigned gy, unsigned nb)
+                                                              const int *status, unsigned gx, unsigned gy, unsigned nb,
+                                                              const int *colmap = nullptr, T *const *xtable = nullptr)
 {
+    // colmap != nullptr: the LAST block-level update of an inversion writes the result itself -- column col of the working copy is
+    // column colmap[col] of the inverse (matinv_bgj_colmap) -- into the caller's buffers (xtable: pointer table, else Xnew / new_stride)
     const XcdTile tile = xcd_tile_of(blockIdx.x, gx, gy, nb);  // tiles of one tile row share their G slab: one XCD (slab_mma.hpp)
     if (!tile.valid) return;
     typedef TileGeo<T> G;
@@ -399,7 +402,8 @@ __global__ __launch_bounds__(256, MTC * MTR <= 4 ? MATINV_BGJ_OCC : 2) void mati
     if (status[item] != 0) return;
     const int j0 = tile.x * TSC, i0 = tile.y * TSR;  // first column / row of the tile
     const T *xold = Xold + item * old_stride;
-    T *xnew = Xnew + item * new_stride;
+    T *xnew = (colmap && xtable) ? xtable[item] : Xnew + item * new_stride;
+    const int *cmap = colmap ? colmap + item * (size_t)n : nullptr;
     const T *g = Gsrc + item * g_stride;
     const T *bsrc = Bsrc + item * b_stride;  // [k][column], ld = ldb: the pivot rows x_old[rmap[Z0 + k]][.] in pivot order
     const int *rm = rmap + item * (size_t)n;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256, MTC * MTR <= 4 ? MATINV_BGJ_OCC : 2) void mati
             if (INNER && skipped) continue;
             const size_t cb = (size_t)col * n;
             const T *xo = xold + cb;
-            T *xn = xnew + cb + row0;
+            T *xn = xnew + (cmap ? (size_t)cmap[col] * n : cb) + row0;
             const T *gc = g + (size_t)(skipped ? col - skip0 : 0) * n + row0;
 #pragma unroll
             for (int v = 0; v < MTR; ++v) {
@@ -538,6 +542,35 @@ __global__ __launch_bounds__(256) void matinv_bgj_finish(const T *W, BatchRef<T>
         for (int r = t & 63; r < n; r += 64) dst[r] = bad ? nan_of<T>() : colsrc[r];
     }
     if (info && blockIdx.x == 0 && t == 0) info[first + item] = bad;
+}
+
+// The column permutation of matinv_bgj_finish folded into the last block-level update (r03: the separate copy was 7 % of a 256^2
+// inversion): colmap[c] = the column of the inverse that column c of the working copy becomes = the pivot swaps applied to c in
+// REVERSE order (the inverse of src above). Also takes over the finish kernel's other duties: info, and NaN for items without a
+// usable pivot (the update kernels skip those). blockDim = n rounded up to a multiple of 64.
+template <class T>
+__global__ __launch_bounds__(1024) void matinv_bgj_colmap(const int *pivots, int *colmap, BatchRef<T> Xout, size_t first, int *info, int n,
+                                                          const int *status)
+{
+    __shared__ int piv[1024];
+    const size_t item = blockIdx.x;
+    const int t = threadIdx.x, bad = status[item];
+    if (info && t == 0) info[first + item] = bad;
+    if (bad) {
+        T *X = Xout.at(first + item);
+        for (size_t e = t; e < (size_t)n * n; e += blockDim.x) X[e] = nan_of<T>();
+        return;
+    }
+    if (t < n) piv[t] = pivots[item * (size_t)n + t];
+    __syncthreads();
+    if (t < n) {
+        int idx = t;
+        for (int k = n - 1; k >= 0; --k) {
+            const int p = piv[k];
+            idx = (idx == k) ? p : ((idx == p) ? k : idx);
+        }
+        colmap[item * (size_t)n + t] = idx;
+    }
 }
 
 // workspace cap of the blocked paths (bytes); MATINV_BLOCKED_WS_MB overrides the 16 GiB default (tests use it to force chunking)
@@ -653,6 +686,7 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
             hipLaunchKernelGGL(matinv_bgj_init<T>, dim3(64, b), dim3(256), 0, stream, A, first, W0, n, status);
             cur = W0;
         }
+        bool fused_finish = false;
         for (int K0 = 0; K0 < n; K0 += nbw) {
             const int bw = n - K0 < nbw ? n - K0 : nbw;
             // the block's sub-panels, inside the block buffers: X0 = the block columns of cur, then P0, P1, P0, ...
@@ -679,13 +713,24 @@ hipError_t launch_gj_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t b
             if (bw < n)
                 hipLaunchKernelGGL(matinv_bgj_pivot_rows<T>, dim3((n + BGJ_PRW - 1) / BGJ_PRW, b), dim3(256), 0, stream, cur, cur_stride, Bfull,
                                    cprev, n, bw, K0, status);
+            // the last of several block-level updates writes the inverse itself (a single block reads the caller's input in place:
+            // no fusion there, input and output may be the same buffer)
+            if (K0 + bw == n && K0 > 0) {
+                fused_finish = true;
+                hipLaunchKernelGGL(matinv_bgj_colmap<T>, dim3(b), dim3(threads), 0, stream, pivots, rowsrc, X, first, info, n, status);
+                T *xbase = X.table ? nullptr : X.base + first * X.stride;
+                hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 2>), dim3(xcd_tile_grid(g, g, b)), dim3(256), 0, stream, cur, cur_stride, xbase,
+                                   X.stride, pin, blk, Bfull, blk, n, cprev, n, n, bw, K0, K0, status, g, g, b, rowsrc,
+                                   X.table ? X.table + first : nullptr);
+                break;
+            }
             hipLaunchKernelGGL((matinv_bgj_update_mfma<T, false, 2>), dim3(xcd_tile_grid(g, g, b)), dim3(256), 0, stream, cur, cur_stride, nxt, nn, pin,
                                blk, Bfull, blk, n, cprev, n, n, bw, K0, K0, status, g, g, b);
             cur = nxt;
             cur_stride = nn;
             nxt = (nxt == W1) ? W0 : W1;
         }
-        hipLaunchKernelGGL(matinv_bgj_finish<T>, dim3(g, b), dim3(256), 0, stream, cur, X, first, pivots, info, n, status);
+        if (!fused_finish) hipLaunchKernelGGL(matinv_bgj_finish<T>, dim3(g, b), dim3(256), 0, stream, cur, X, first, pivots, info, n, status);
     }
     e = hipGetLastError();
     hipError_t e2 = scratch_free(ws, stream), e3 = scratch_free(iws, stream);

@@ -766,6 +766,45 @@ def test_reference_device_table_family(uniform):
         assert rel_err(got, want, n) < 1e-10, name
 
 
+@pytest.mark.parametrize("uniform", [True, False])
+def test_reference_device_table_family_blocked_sizes(uniform):
+    """The same dispatch point at a size the blocked paths serve (n = 200: two 128-column blocks): a GENERAL batch through
+    inverse_gauss_batched_device -- uniform pitch > n^2 = strided input read in place by the first block, scattered pointers = the
+    gathering copy; either way the last block-level update writes the permuted columns straight into the caller's buffers (r03) --
+    and an SPD batch through inverse_cholesky_batched_device. One singular item: info is not reported through this family, its
+    result is NaN and its neighbours are untouched."""
+    n, batch = 200, 6
+    L = pkg("_lib").lib()
+    g = general_batch(n, batch, seed=77).reshape(batch, n, n)
+    g[4, 11, :] = 0.0                      # column 11 of item 4 (memory is [k, col, row])
+    spd = spd_batch(n, batch, seed=78)
+    pitch = n * n + (40 if uniform else 0)
+    slot = n * n + 128
+    d_in = torch.zeros(batch * slot, dtype=torch.float64, device="cuda")
+    d_out = torch.zeros_like(d_in)
+    offs = [i * pitch for i in range(batch)] if uniform else [((i * 5) % batch) * slot for i in range(batch)]
+    tin = _table([d_in.data_ptr() + 8 * o for o in offs])
+    tout = _table([d_out.data_ptr() + 8 * o for o in offs])
+    for name, a, oalgo in (("inverse_gauss_batched_device", g.reshape(-1), oracle.ALGO_GJ_PIVOT),
+                           ("inverse_cholesky_batched_device", spd, oracle.ALGO_CHOLESKY)):
+        d_in.zero_()
+        d_out.zero_()
+        for i, o in enumerate(offs):
+            d_in[o:o + n * n] = torch.from_numpy(a[i * n * n:(i + 1) * n * n]).cuda()
+        torch.cuda.synchronize()
+        getattr(L, name)(None, n, tin, tout, batch)
+        torch.cuda.synchronize()
+        res = d_out.cpu().numpy()
+        got = np.concatenate([res[o:o + n * n] for o in offs])
+        keep = [i for i in range(batch) if not (name.startswith("inverse_gauss") and i == 4)]
+        want, _ = oracle.inverse_batched(np.concatenate([a[i * n * n:(i + 1) * n * n] for i in keep]), n, oalgo)
+        gk = np.concatenate([got[i * n * n:(i + 1) * n * n] for i in keep])
+        cond = max(np.linalg.cond(m) for m in as_mats(np.concatenate([a[i * n * n:(i + 1) * n * n] for i in keep]), n))
+        assert rel_err(gk, want, n) < max(1e-10, 1e-15 * cond * n), name
+        if len(keep) < batch:
+            assert np.isnan(got[4 * n * n:5 * n * n]).all()
+
+
 def test_cholesky_subphase_entry_points():
     """decompose / inverse_upper / multiply_upper (inverse_gpu.h:15-24): in place, lower triangle, upper zeroed."""
     n, batch = 24, 6
