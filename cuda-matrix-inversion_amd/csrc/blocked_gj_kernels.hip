@@ -313,7 +313,12 @@ __global__ __launch_bounds__(1024) void matinv_bgj_panel(const T *Pin, size_t in
         if (t < bw && (t < c0 || t >= c0 + pb)) {
             const T *col = pin + (size_t)t * n;
             T *b = Bin + item * (size_t)BGJ_PB * BGJ_NB;
-            for (int j = 0; j < pb; ++j) b[(size_t)j * BGJ_NB + t] = col[rs[kg0 + j]];
+            T v[BGJ_PB];  // all loads in flight at once (a run-time loop issued them one memory latency after the other)
+#pragma unroll
+            for (int j = 0; j < BGJ_PB; ++j) v[j] = col[rs[kg0 + (j < pb ? j : 0)]];
+#pragma unroll
+            for (int j = 0; j < BGJ_PB; ++j)
+                if (j < pb) b[(size_t)j * BGJ_NB + t] = v[j];
         }
     }
 }
