@@ -254,6 +254,7 @@ __global__ __launch_bounds__(1024) void matinv_bgj_panel(const T *Pin, size_t in
 #pragma unroll
     for (int c = 0; c < BGJ_PB; ++c) x[c] = (t < n && c < pb) ? pin[(size_t)(c0 + c) * n + t] : (T)0;
     rs[t] = t;
+    if (t < 16) { s_val[t] = (T)-1; s_idx[t] = 0; }  // slots of waves that do not exist never win the scan below
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < BGJ_PB; ++j) {
@@ -263,12 +264,18 @@ __global__ __launch_bounds__(1024) void matinv_bgj_panel(const T *Pin, size_t in
             const int bi = (t & ~63) + bgj_wave_argmax_abs(x[j], t >= k && t < n, &best);
             if (tx == 0) { s_val[ty] = best; s_idx[ty] = bi; }
             __syncthreads();
-            best = s_val[0];
-            int p = s_idx[0];
-            for (int w = 1; w < nwaves; ++w) {
-                const T ob = s_val[w];
-                const int oi = s_idx[w];
-                if (ob > best) { best = ob; p = oi; }  // equal maxima: the lower wave (lower rows) keeps it
+            // scan of the per-wave maxima, four slots per trip so that their LDS reads are in flight together (one slot per trip cost
+            // 15 dependent LDS latencies per pivot at n = 1024)
+            best = (T)-1;
+            int p = 0;
+            for (int w0 = 0; w0 < nwaves; w0 += 4) {
+                T ob[4];
+                int oi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ob[u] = s_val[w0 + u]; oi[u] = s_idx[w0 + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ob[u] > best) { best = ob[u]; p = oi[u]; }  // equal maxima: the lower wave (lower rows) keeps it
             }
             if (!(best > 0) || best > max_finite<T>()) {  // zero, NaN or infinite column: no usable pivot (block-uniform)
                 if (t == 0) status[item] = k + 1;
