@@ -651,6 +651,31 @@ def test_strided_batch_and_in_place():
     assert rel_err(d_in.cpu().numpy().reshape(batch, stride)[:, : n * n].reshape(-1), want, n) < 1e-10
 
 
+@pytest.mark.parametrize("n", [24, 50, 64, 100, 128, 150, 192, 200, 300])
+def test_strided_batch_and_in_place_every_family(n):
+    """The same contract (matinv.h: matrix k at k * stride, padding never written, exact aliasing of input and output allowed) at a
+    size of every kernel family, general input through Gauss-Jordan and SPD input through Cholesky. The blocked Gauss-Jordan reads a
+    strided batch in place during its first block and writes the caller's buffer from its last block-level update (r03)."""
+    batch, stride = 5, n * n + 40
+    for algo, oalgo, a in ((GJ, oracle.ALGO_GJ_PIVOT, general_batch(n, batch, seed=n)), (CH, oracle.ALGO_CHOLESKY, spd_batch(n, batch, seed=n))):
+        want, _ = oracle.inverse_batched(a, n, oalgo)
+        cond = max(np.linalg.cond(m) for m in as_mats(a, n))
+        tol = max(1e-10, 1e-15 * cond * n)
+        buf = np.full((batch, stride), 123.0)
+        buf[:, : n * n] = a.reshape(batch, n * n)
+        d_in = dev(buf.reshape(-1))
+        d_out = torch.full_like(d_in, -5.0)
+        api.inverse_batched(d_in, n, algo, out=d_out, batch=batch, stride=stride)
+        res = d_out.cpu().numpy().reshape(batch, stride)
+        assert rel_err(res[:, : n * n].reshape(-1), want, n) < tol, (algo, n)
+        assert (res[:, n * n:] == -5.0).all(), "padding between matrices was written"
+        assert np.array_equal(d_in.cpu().numpy(), buf.reshape(-1)), "input batch was modified"
+        api.inverse_batched(d_in, n, algo, out=d_in, batch=batch, stride=stride)
+        back = d_in.cpu().numpy().reshape(batch, stride)
+        assert rel_err(back[:, : n * n].reshape(-1), want, n) < tol, (algo, n, "in place")
+        assert (back[:, n * n:] == 123.0).all()
+
+
 @pytest.mark.parametrize("n", [8, 16, 32, 64, 100, 128, 200])
 def test_nan_and_inf_inputs_are_reported_not_propagated(n):
     """A NaN or an Inf inside one matrix: that matrix is reported (info != 0, result all NaN) by every family on the
