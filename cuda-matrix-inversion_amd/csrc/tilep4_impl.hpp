@@ -75,16 +75,16 @@ __device__ __forceinline__ void gather_zero_tile_row2(typename TileGeo<T>::vec4 
 #undef TP4_W64
 }
 
-template <class T, int NT, bool FULL>
+template <class T, int NT, bool FULL, int W = 4>
 __device__ __forceinline__ void gj_tilep4_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
                                                T *panel2, T *bball, unsigned char *tab, int *bad_count, int *bad_list,
                                                const int *in_count, const int *in_list, hint_t *hint_out)
 {
-    static_assert(NT >= 5 && NT <= 8, "four wavefronts serve 64 < n <= 128");
+    static_assert(NT >= 5 && NT <= 2 * W && W <= 4, "W wavefronts of two tile columns each serve 64 < n <= 32 W");
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
     constexpr int N = 16 * NT;
-    constexpr int W = 4, NC = 2;
+    constexpr int NC = 2;
     unsigned char *const rowaddr = tab, *const coladdr = tab + 128;
     const int l = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;  // wave-uniform
@@ -360,6 +360,29 @@ __global__ __launch_bounds__(256, NT <= 7 ? 3 : 2) void matinv_gj_tilep4_f64(Bat
     gj_tilep4_body<double, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out);
 }
 
+// THREE wavefronts per matrix for 5 x 5 / 6 x 6 tiles (r03): with four, the tile columns fall 2 + 1 + 1 + 1 / 2 + 2 + 1 + 1 on the waves and
+// the block step lasts as long as the wave with two; with three (2 + 2 + 1 / 2 + 2 + 2) a CU holds four matrices instead of three
+template <int NT, bool FULL>
+__global__ __launch_bounds__(192, 3) void matinv_gj_tilep3_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
+                                                              unsigned batch, int *bad_count, int *bad_list, const int *in_count,
+                                                              const int *in_list, hint_t *hint_out)
+{
+    __shared__ __attribute__((aligned(16))) double panel2[2 * 16 * NT * 4];
+    __shared__ __attribute__((aligned(16))) double bball[3 * 4 * 32];
+    __shared__ unsigned char tab[256];
+    gj_tilep4_body<double, NT, FULL, 3>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out);
+}
+template <int NT, bool FULL>
+__global__ __launch_bounds__(192, 3) void matinv_gj_tilep3_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n_rt,
+                                                              unsigned batch, int *bad_count, int *bad_list, const int *in_count,
+                                                              const int *in_list, hint_t *hint_out)
+{
+    __shared__ __attribute__((aligned(16))) float panel2[2 * 16 * NT * 4];
+    __shared__ __attribute__((aligned(16))) float bball[3 * 4 * 32];
+    __shared__ unsigned char tab[256];
+    gj_tilep4_body<float, NT, FULL, 3>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out);
+}
+
 template <int NT, bool FULL>
 __global__ __launch_bounds__(256, 3) void matinv_gj_tilep4_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info, int n_rt,
                                                               unsigned batch, int *bad_count, int *bad_list, const int *in_count,
@@ -371,13 +394,23 @@ __global__ __launch_bounds__(256, 3) void matinv_gj_tilep4_f32(BatchRef<const fl
     gj_tilep4_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out);
 }
 
+// MATINV_TILEP_W3=0: four wavefronts per matrix also at 5 x 5 / 6 x 6 tiles (A/B switch)
+static inline bool tilep_three_waves()
+{
+    static const bool on = []() {
+        const char *s = getenv("MATINV_TILEP_W3");
+        return !(s && *s == '0');
+    }();
+    return on;
+}
+
 template <class T>
 static hipError_t enqueue_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *bad_count,
                                  int *bad_list, const int *in_count, const int *in_list, hint_t *hint_out)
 {
     const int nt = (n + 15) / 16;
-    unsigned cap = 256u * 3u * tile_grid_rounds();
-    if (in_list) cap = 256u * 3u;  // usually empty: one round of resident workgroups
+    unsigned cap = 256u * 4u * tile_grid_rounds();
+    if (in_list) cap = 256u * 4u;  // usually empty: one round of resident workgroups
     const unsigned grid = (unsigned)(batch < cap ? batch : cap);
     const unsigned b = (unsigned)batch;
 #define TP4_LAUNCH(NT_)                                                                                                \
@@ -392,13 +425,26 @@ static hipError_t enqueue_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size
         else                                                                                                           \
             hipLaunchKernelGGL((matinv_gj_tilep4_f32<NT_, false>), dim3(grid), dim3(256), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
     }
+#define TP3_LAUNCH(NT_)                                                                                                \
+    if constexpr (sizeof(T) == 8) {                                                                                    \
+        if (n == 16 * NT_)                                                                                             \
+            hipLaunchKernelGGL((matinv_gj_tilep3_f64<NT_, true>), dim3(grid), dim3(192), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((matinv_gj_tilep3_f64<NT_, false>), dim3(grid), dim3(192), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
+    } else {                                                                                                           \
+        if (n == 16 * NT_)                                                                                             \
+            hipLaunchKernelGGL((matinv_gj_tilep3_f32<NT_, true>), dim3(grid), dim3(192), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((matinv_gj_tilep3_f32<NT_, false>), dim3(grid), dim3(192), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
+    }
     switch (nt) {
-    case 5: TP4_LAUNCH(5) break;
-    case 6: TP4_LAUNCH(6) break;
+    case 5: if (tilep_three_waves()) { TP3_LAUNCH(5) } else { TP4_LAUNCH(5) } break;
+    case 6: if (tilep_three_waves()) { TP3_LAUNCH(6) } else { TP4_LAUNCH(6) } break;
     case 7: TP4_LAUNCH(7) break;
     default: TP4_LAUNCH(8) break;
     }
 #undef TP4_LAUNCH
+#undef TP3_LAUNCH
     return hipGetLastError();
 }
 

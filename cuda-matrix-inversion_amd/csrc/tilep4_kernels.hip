@@ -42,7 +42,9 @@ hipError_t launch_gj_tilep4_worklist<double>(int n, BatchRef<const double> A, Ba
 const char *name_gj_tilep4(bool f64, int n)
 {
     static thread_local char buf[48];
-    snprintf(buf, sizeof buf, "matinv_gj_tilep4_%s<%d, %s>", f64 ? "f64" : "f32", (n + 15) / 16, (n % 16) == 0 ? "true" : "false");
+    const int nt = (n + 15) / 16;
+    snprintf(buf, sizeof buf, "matinv_gj_tilep%d_%s<%d, %s>", (nt <= 6 && tilep_three_waves()) ? 3 : 4, f64 ? "f64" : "f32", nt,
+             (n % 16) == 0 ? "true" : "false");
     return buf;
 }
 

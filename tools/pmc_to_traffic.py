@@ -43,7 +43,7 @@ for kern, (_, v) in best.items():
         continue
     rd, wr = 2.0 * v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
     n = {"matinv_gj_tile_f64": 16, "matinv_spd_tile_f64": 16, "matinv_gj_tile4_f64": 16, "matinv_gj_tilep_f64": 16,
-         "matinv_gj_tilep4_f64": 16, "matinv_gj_tilepb_f64": 16, "matinv_gj_tilepw_f64": 16}.get(kern.split("<")[0], 1) * int(m.group(1))
+         "matinv_gj_tilep4_f64": 16, "matinv_gj_tilep3_f64": 16, "matinv_gj_tilepb_f64": 16, "matinv_gj_tilepw_f64": 16}.get(kern.split("<")[0], 1) * int(m.group(1))
     if (rd + wr) < 0.1 * batch * 2 * n * n * 8:
         continue  # a launch that moved (almost) nothing: an empty work-list pass, not this kernel's job
     table[f"{kern}|n={n}"] = rd + wr
