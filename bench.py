@@ -48,6 +48,7 @@ WORKLOADS = {
     # matrix needs row exchanges
     "gj64g": (64, "gj", "batch x 64x64 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
     "gj32g": (32, "gj", "batch x 32x32 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
+    "gj96g": (96, "gj", "batch x 96x96 fp64 Gauss-Jordan with partial pivoting (three wavefronts per matrix), GENERAL U(0,1) inputs"),
     "gj128g": (128, "gj", "batch x 128x128 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
     "gj192g": (192, "gj", "batch x 192x192 fp64 Gauss-Jordan with partial pivoting (one wavefront per tile column), GENERAL U(0,1) inputs"),
     "chol192": (192, "chol", "batch x 192x192 fp64 Cholesky inverse (one wavefront per tile column), SPD inputs"),
@@ -56,7 +57,7 @@ WORKLOADS = {
     "chol256": (256, "chol", "batch x 256x256 fp64 blocked Cholesky inverse, SPD inputs"),
     "chol1024": (1024, "chol", "batch x 1024x1024 fp64 blocked Cholesky inverse (panel pairs, rank-128 update, Y Y^T product), SPD inputs"),
 }
-GENERAL = {"gj64g", "gj32g", "gj128g", "gj192g", "gj256g", "gj1024g"}
+GENERAL = {"gj64g", "gj32g", "gj96g", "gj128g", "gj192g", "gj256g", "gj1024g"}
 
 
 def make_spd(n, batch, seed, device):
@@ -539,7 +540,7 @@ def main():
             del a2, x2
             return d
 
-        for wname in ("gj16", "chol64", "gj32", "gj24", "gj50", "gj8", "gj128", "gj64g", "gj32g", "gj128g", "gj192g", "chol192", "gj256g", "chol256",
+        for wname in ("gj16", "chol64", "gj32", "gj24", "gj50", "gj8", "gj128", "gj64g", "gj32g", "gj96g", "gj128g", "gj192g", "chol192", "gj256g", "chol256",
                       "gj1024g", "chol1024"):
             if wname == args.workload:
                 continue
