@@ -345,6 +345,9 @@ __global__ __launch_bounds__(64 * W, W > 4 ? 1 : (W <= 2 ? 2 : 3)) void matinv_g
 // Beyond 8 tiles per dimension (r02: the Cholesky entry point and the fused pipeline up to n = 192 in f64, 256 in f32) every
 // wavefront holds ONE tile column: NT wavefronts per matrix, one workgroup per CU. An f64 matrix of 12 x 12 tiles is 1 152 of
 // the CU's 2 048 VGPRs per lane; 13 x 13 no longer leaves room for the working registers of 13 waves.
+// (r03, measured and not kept: fp32 9 ... 12 tiles per dimension with TWO tile columns per wave and (NT + 1) / 2 waves, three waves per
+// SIMD so that two matrices fit a CU: 130^2 / 160^2 4.85e6 / 3.76e6 inv/s against 4.95e6 / 3.83e6, and 176^2 / 192^2 1.9e6 / 1.65e6
+// against 3.0e6 / 2.66e6 -- 200+ B of scratch there, and every wave's redundant panel solve now serves two columns' worth of waiting)
 constexpr int t4_waves(bool f64, int nt) { return nt > 8 ? nt : (f64 ? (nt <= 6 ? 2 : 4) : (nt <= 5 ? 1 : (nt <= 7 ? 2 : 4))); }
 constexpr int t4_wide_limit(bool f64) { return f64 ? 192 : 256; }
 // the fused pipeline in f32 stops at 13 x 13 tiles: at 256 the blocked path is faster (1.4e6 items/s against 1.0e6)
