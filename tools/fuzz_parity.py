@@ -1,5 +1,5 @@
 """One-off randomized parity campaign against the CPU oracle (not part of the test suite): random dtype / algorithm / size / input
-class per trial; prints every failure and a summary. usage: python tools/fuzz_parity.py [trials] [seed]"""
+class per trial; prints every failure and a summary. usage: python tools/fuzz_parity.py [trials] [seed] [nmax]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -10,13 +10,14 @@ from conftest import spd_batch, general_batch, rel_err, as_mats
 api = importlib.import_module("cuda-matrix-inversion_amd.api")
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 320  # sizes beyond 320 (up to 1024) only when asked for: the oracle takes seconds there
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fails = 0
 for it in range(trials):
-    n = int(rng.choice([rng.integers(1, 33), rng.integers(33, 129), rng.integers(129, 200), rng.integers(200, 321)], p=[0.3, 0.35, 0.2, 0.15]))
+    n = int(rng.choice([rng.integers(1, 33), rng.integers(33, 129), rng.integers(129, 200), rng.integers(200, nmax + 1)], p=[0.3, 0.35, 0.2, 0.15] if nmax <= 320 else [0.05, 0.1, 0.15, 0.7]))
     dt = np.float64 if rng.random() < 0.55 else np.float32
     what = rng.choice(["gj_spd", "gj_gen", "chol", "mean", "var"], p=[0.2, 0.3, 0.2, 0.2, 0.1])
-    batch = int(rng.integers(1, 40 if n < 130 else 9))
+    batch = int(rng.integers(1, 40 if n < 130 else (9 if n <= 320 else 4)))
     seed = int(rng.integers(1 << 30))
     tol32 = 5e-4 if what == "gj_gen" else 5e-5
     detail = ""
