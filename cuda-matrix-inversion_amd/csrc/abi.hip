@@ -74,7 +74,7 @@ int select_auto(int algo, int n)
     if (algo == MATINV_ALGO_GAUSS_JORDAN) {
         if (rowlane_family_supports<T>(n)) return MATINV_KERNEL_ROWLANE;
         if (tile_family_supports<T>(n)) return MATINV_KERNEL_TILE;
-        if (tilepw_supports(sizeof(T) == 8, n)) return MATINV_KERNEL_TILEP;  // one wavefront per tile column, pivoting
+        if (tileq_supports(sizeof(T) == 8, n)) return MATINV_KERNEL_TILEP;  // one wavefront per tile column, pivoting
         if (blocked_gj_supports(n)) return MATINV_KERNEL_BLOCKED;  // beyond n = 128 it beats the LDS kernel at every size measured
     } else if (rowlane_family_supports<T>(n)) {
         return MATINV_KERNEL_ROWLANE;  // several SPD matrices per wavefront
@@ -147,9 +147,9 @@ int inverse_dispatch(int algo, int n, BatchRef<const T> A, BatchRef<T> X, size_t
         e = launch_chol_blocked<T>(n, A, X, batch, dInfo, stream);
         break;
     case MATINV_KERNEL_TILEP:
-        if (algo != MATINV_ALGO_GAUSS_JORDAN || !(tilep_supports(n) || tilepw_supports(sizeof(T) == 8, n)))
+        if (algo != MATINV_ALGO_GAUSS_JORDAN || !(tilep_supports(n) || tileq_supports(sizeof(T) == 8, n)))
             return fail(MATINV_ERR_UNSUPPORTED, "pivoting tile family serves Gauss-Jordan with n <= 192 (f64) / 256 (f32) only (n=%d)", n);
-        e = n > 128 ? launch_gj_tilepw<T>(n, A, X, batch, dInfo, stream)
+        e = n > 128 ? launch_gj_tileq<T>(n, A, X, batch, dInfo, stream, nullptr, nullptr, nullptr, nullptr, nullptr)
                     : (n > 64 ? launch_gj_tilep4<T>(n, A, X, batch, dInfo, stream) : launch_gj_tilep<T>(n, A, X, batch, dInfo, stream));
         break;
     case MATINV_KERNEL_ROW:
@@ -662,7 +662,7 @@ int gp_host(int n, const void *hA, const void *hB, const void *hC, const void *h
 template <class T>
 int lu_kernel(int n)
 {
-    return (n > 16 && (tilep_supports(n) || tilepw_supports(sizeof(T) == 8, n))) ? (int)MATINV_KERNEL_TILEP : (int)MATINV_KERNEL_AUTO;
+    return (n > 16 && (tilep_supports(n) || tileq_supports(sizeof(T) == 8, n))) ? (int)MATINV_KERNEL_TILEP : (int)MATINV_KERNEL_AUTO;
 }
 
 // Reference error contract: message on stderr, then exit (include/helper_gpu.h:9-18, helper_cpu.h:12-21 there).
@@ -811,7 +811,7 @@ const char *matinv_kernel_name(int algo, int dtype, int n, int kernel)
     case MATINV_KERNEL_ROWLANE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_rowlane(f64, n) : name_gj_rowlane(f64, n);
     case MATINV_KERNEL_TILE: return algo == MATINV_ALGO_CHOLESKY ? name_spd_tile(f64, n) : name_gj_tile(f64, n);
     case MATINV_KERNEL_ROW: return name_gj_row(f64, n);
-    case MATINV_KERNEL_TILEP: return n > 128 ? name_gj_tilepw(f64, n) : name_gj_tilep(f64, n);
+    case MATINV_KERNEL_TILEP: return n > 128 ? name_gj_tileq(f64, n) : name_gj_tilep(f64, n);
     case MATINV_KERNEL_GLOBAL: return algo == MATINV_ALGO_CHOLESKY ? name_chol_global(f64) : name_gj_global(f64);
     case MATINV_KERNEL_BLOCKED:
         if (algo == MATINV_ALGO_GAUSS_JORDAN) {

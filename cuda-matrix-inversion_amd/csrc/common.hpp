@@ -219,49 +219,21 @@ hipError_t launch_gj_tilep4_worklist<float>(int n, BatchRef<const float> A, Batc
                                             const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
                                             hint_t *hint_out);
 const char *name_gj_tilep4(bool f64, int n);
-int tilep_variant();  // MATINV_TILEP_WAVES: 0 = default, 1 = "col" (tilepw for 64 < n <= 128), 2 = "blk" (tilepb) -- A/B switch
-// one wavefront per tile column, 128 < n <= 192 (f64) / 256 (f32), general matrices (tilepw_kernels.hip)
-bool tilepw_supports(bool f64, int n);
+// r04: fixed pivot rows, searched pivot columns -- no run-time register index (tileq_kernels.hip): one wavefront per tile column,
+// general 128 < n <= 192 (f64) / 256 (f32). in_count / in_list: work-list form (nullptr: the whole batch); bad_count / bad_list: unused
+// at these sizes (the kernel finishes a singular matrix itself), kept for the n <= 128 instantiations of tools/tileq_stamps.hip
 template <class T>
-hipError_t launch_gj_tilepw(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
+hipError_t launch_gj_tileq(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, const int *in_count,
+                           const int *in_list, hint_t *hint_out, int *bad_count, int *bad_list);
 template <>
-hipError_t launch_gj_tilepw<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
+hipError_t launch_gj_tileq<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream,
+                                   const int *in_count, const int *in_list, hint_t *hint_out, int *bad_count, int *bad_list);
 template <>
-hipError_t launch_gj_tilepw<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
-template <class T>
-hipError_t launch_gj_tilepw_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count, const int *in_list,
-                                     int *info, hipStream_t stream, hint_t *hint_out);
-template <>
-hipError_t launch_gj_tilepw_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
-                                             const int *in_list, int *info, hipStream_t stream, hint_t *hint_out);
-template <>
-hipError_t launch_gj_tilepw_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
-                                            const int *in_list, int *info, hipStream_t stream, hint_t *hint_out);
-const char *name_gj_tilepw(bool f64, int n);
-// one wavefront per tile column, one tile column (16 pivots) per workgroup barrier, 64 < n <= 192 (f64) / 256 (f32)
-// (tilepb_kernels.hip); in_count / in_list: work-list form
-template <class T>
-hipError_t launch_gj_tilepb(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
-                            const int *in_count = nullptr, const int *in_list = nullptr, hint_t *hint_out = nullptr);
-template <>
-hipError_t launch_gj_tilepb<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream,
-                                    const int *in_count, const int *in_list, hint_t *hint_out);
-template <>
-hipError_t launch_gj_tilepb<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream,
-                                   const int *in_count, const int *in_list, hint_t *hint_out);
-const char *name_gj_tilepb(bool f64, int n);
-// second-generation natural-order tile kernel, n <= 64 (tilen_kernels.hip): enqueue only, the caller owns the work list
-template <class T>
-hipError_t enqueue_gj_tilen(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *work_count,
-                            int *work_list);
-template <>
-hipError_t enqueue_gj_tilen<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream,
-                                    int *work_count, int *work_list);
-template <>
-hipError_t enqueue_gj_tilen<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream,
-                                   int *work_count, int *work_list);
-bool tile_natural_old();  // MATINV_TILE_NATURAL=old: the r01 kernel of tile_kernels.inc (A/B measurements)
-const char *name_gj_tilen(bool f64, int n);
+hipError_t launch_gj_tileq<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream,
+                                  const int *in_count, const int *in_list, hint_t *hint_out, int *bad_count, int *bad_list);
+const char *name_gj_tileq(bool f64, int n);
+// general 128 < n <= 192 (f64) / 256 (f32): TILEQ (tileq_kernels.hip)
+bool tileq_supports(bool f64, int n);
 // Adaptive choice between the natural-order (verified) tile kernel and the pivoting one (tile_kernels.hip): see gj_tile_policy
 struct TileStats {
     unsigned long long natural_launches, pivot_launches, last_rejected, last_batch;

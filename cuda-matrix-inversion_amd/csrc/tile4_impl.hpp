@@ -48,7 +48,7 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
     static_assert(!GP || SPD, "the fused pipeline runs the SPD sweep");
     // NT > 8, SPD sweep: no Cholesky kernel behind this one serves every such n, so a matrix that is not positive definite is
     // finished here: info = the column of the first non-positive pivot + 1 (the Cholesky contract), output NaN-filled.
-    // (Gauss-Jordan, NT > 8: rejected = needs row exchanges -> work list -> the pivoting kernel of that size, tilepw_impl.hpp)
+    // (Gauss-Jordan, NT > 8: rejected = needs row exchanges -> work list -> the pivoting kernel of that size, tileq_impl.hpp)
     constexpr bool SELF = NT > 8 && SPD;
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
@@ -361,7 +361,8 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
     // Gauss-Jordan: general batches go straight to the PIVOTING kernel of this size once a natural-order launch of this size
     // has seen most of its matrices rejected (tile_kernels.inc "natural order or pivot search?")
     if (!SPD && tile_policy_use_pivot(sizeof(T) == 8, (n + 15) / 16))
-        return n > 128 ? launch_gj_tilepw<T>(n, A, X, batch, info, stream) : launch_gj_tilep4<T>(n, A, X, batch, info, stream);
+        return n > 128 ? launch_gj_tileq<T>(n, A, X, batch, info, stream, nullptr, nullptr, nullptr, nullptr, nullptr)
+                       : launch_gj_tilep4<T>(n, A, X, batch, info, stream);
     // [0], [1] = counts; [2 .. batch+2) = rejected matrices; [batch+2 ..) = (Gauss-Jordan) the singular ones among them
     int *ws = nullptr;
     hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (2 * batch + 2) * sizeof(int), stream);
@@ -419,7 +420,7 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
             e = launch_gj_tilep4_worklist<T>(n, A, X, batch, ws, ws + 2, ws + 1, ws + 2 + batch, info, stream,
                                              tile_policy_record(sizeof(T) == 8, nt, batch));
         } else {
-            e = launch_gj_tilepw_worklist<T>(n, A, X, batch, ws, ws + 2, info, stream, tile_policy_record(sizeof(T) == 8, nt, batch));
+            e = launch_gj_tileq<T>(n, A, X, batch, info, stream, ws, ws + 2, tile_policy_record(sizeof(T) == 8, nt, batch), nullptr, nullptr);
         }
     }
     hipError_t e2 = scratch_free(ws, stream);

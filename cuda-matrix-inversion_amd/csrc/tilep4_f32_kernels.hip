@@ -1,4 +1,4 @@
-// tilep4_f32_kernels.hip -- fp32 instantiations of the four-wavefront pivoting MFMA tile kernels (tilep4_impl.hpp).
+// tilep4_f32_kernels.hip -- fp32 instantiations of the three- / four-wavefront pivoting MFMA tile kernels (tilep4_impl.hpp).
 #include "tilep4_impl.hpp"
 
 namespace matinv {
@@ -6,18 +6,14 @@ namespace matinv {
 template <>
 hipError_t launch_gj_tilep4<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream)
 {
-    if (tilep_variant() == 2) return launch_gj_tilepb<float>(n, A, X, batch, info, stream);
-    if (tilep_variant() == 1) return launch_gj_tilepw<float>(n, A, X, batch, info, stream);
     return launch_tilep4<float>(n, A, X, batch, info, stream);
 }
 
 template <>
 hipError_t launch_gj_tilep4_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
-                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                            hint_t *hint_out)
+                                           const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
+                                           hint_t *hint_out)
 {
-    if (tilep_variant() == 2) return launch_gj_tilepb<float>(n, A, X, batch, info, stream, in_count, in_list, hint_out);
-    if (tilep_variant() == 1) return launch_gj_tilepw_worklist<float>(n, A, X, batch, in_count, in_list, info, stream, hint_out);
     return launch_tilep4_worklist<float>(n, A, X, batch, in_count, in_list, bad_count, bad_list, info, stream, hint_out);
 }
 

@@ -14,7 +14,7 @@
 // (Measured and not kept here: ONE searching wave per block -- the owner -- publishing the finished panel through LDS while the
 // other three only run their MFMAs until the barrier. It removes 3/4 of the search instructions and loses 10 %: 3.8e6 inv/s
 // at 128 x 128 f64 against 4.2e6, 6.1e6 against 6.8e6 at 96 x 96 -- with four waves the search of ONE wave is the critical
-// path either way, and the redundant version needs no second LDS trip. tilepw_impl.hpp, 9-16 waves per matrix, does gain.)
+// path either way, and the redundant version needs no second LDS trip.)
 // Look-ahead as in the one-wave kernel: the local tile column that (for the next owner) holds the next pivot columns is
 // updated first, the next panel is staged, and the other column's MFMAs run pinned between the stages of the next search.
 //
@@ -22,7 +22,6 @@
 // /root/reference/src/gauss/batched_invert.cu:17-82 (the reference's sweep goes to n = 128, Makefile:202-220).
 #pragma once
 #include "tilep_impl.hpp"
-#include "gather_tree.inc"
 
 namespace matinv {
 
@@ -394,16 +393,6 @@ __global__ __launch_bounds__(256, 3) void matinv_gj_tilep4_f32(BatchRef<const fl
     gj_tilep4_body<float, NT, FULL>(Ain, Xout, info, n_rt, batch, panel2, bball, tab, bad_count, bad_list, in_count, in_list, hint_out);
 }
 
-// MATINV_TILEP_W3=0: four wavefronts per matrix also at 5 x 5 / 6 x 6 tiles (A/B switch)
-static inline bool tilep_three_waves()
-{
-    static const bool on = []() {
-        const char *s = getenv("MATINV_TILEP_W3");
-        return !(s && *s == '0');
-    }();
-    return on;
-}
-
 template <class T>
 static hipError_t enqueue_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *bad_count,
                                  int *bad_list, const int *in_count, const int *in_list, hint_t *hint_out)
@@ -438,8 +427,8 @@ static hipError_t enqueue_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size
             hipLaunchKernelGGL((matinv_gj_tilep3_f32<NT_, false>), dim3(grid), dim3(192), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
     }
     switch (nt) {
-    case 5: if (tilep_three_waves()) { TP3_LAUNCH(5) } else { TP4_LAUNCH(5) } break;
-    case 6: if (tilep_three_waves()) { TP3_LAUNCH(6) } else { TP4_LAUNCH(6) } break;
+    case 5: TP3_LAUNCH(5) break;
+    case 6: TP3_LAUNCH(6) break;
     case 7: TP4_LAUNCH(7) break;
     default: TP4_LAUNCH(8) break;
     }

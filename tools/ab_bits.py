@@ -16,5 +16,5 @@ kernel = {"": api.KERNEL_AUTO, "tile": api.KERNEL_TILE, "tilep": api.KERNEL_TILE
 x = api.inverse_batched(a, n, api.ALGO_GAUSS_JORDAN, batch=batch, kernel=kernel)
 torch.cuda.synchronize()
 h = hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest()[:16]
-print(f"n={n} {sys.argv[2] if len(sys.argv) > 2 else 'f64'} {kind} kernel={os.environ.get('MATINV_TIME_KERNEL','auto')} natural={os.environ.get('MATINV_TILE_NATURAL','old')} "
-      f"policy={os.environ.get('MATINV_GJ_POLICY','adaptive')} waves={os.environ.get('MATINV_TILEP_WAVES','4')}: sha {h}  stats {api.tile_stats()}")
+print(f"n={n} {sys.argv[2] if len(sys.argv) > 2 else 'f64'} {kind} kernel={os.environ.get('MATINV_TIME_KERNEL','auto')} "
+      f"policy={os.environ.get('MATINV_GJ_POLICY','adaptive')}: sha {h}  stats {api.tile_stats()}")
