@@ -192,13 +192,15 @@ hipError_t launch_gj_tilep<float>(int n, BatchRef<const float> A, BatchRef<float
 // (bad_count, bad_list), zeroed by the caller; hint_out (pinned host memory, may be null) receives the list length
 template <class T>
 hipError_t launch_gj_tilep_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count, const int *in_list,
-                                    int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out);
+                                    int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out, bool expect_many = false);
 template <>
 hipError_t launch_gj_tilep_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
-                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out);
+                                            const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out,
+                                            bool expect_many);
 template <>
 hipError_t launch_gj_tilep_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
-                                           const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out);
+                                           const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out,
+                                           bool expect_many);
 const char *name_gj_tilep(bool f64, int n);
 // four wavefronts per matrix, 64 < n <= 128 (tilep4_kernels.hip)
 template <class T>

@@ -452,11 +452,14 @@ __global__ __launch_bounds__(64, 3) void matinv_gj_tilep_f32(BatchRef<const floa
 // Singular matrices are appended to (bad_count, bad_list) for the ROW kernel.
 template <class T>
 static hipError_t enqueue_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream,
-                                const int *in_count, const int *in_list, hint_t *hint_out, int *bad_count, int *bad_list)
+                                const int *in_count, const int *in_list, hint_t *hint_out, int *bad_count, int *bad_list, bool expect_many = false)
 {
     const int nt = (n + 15) / 16;
     unsigned cap = 256u * 12u * tile_grid_rounds();
-    if (in_list) cap = 256u * 12u;
+    // work-list form: the list is usually empty -- one round of resident workgroups that stride over it. Behind the screening pass
+    // (expect_many) most of the batch is on it: one workgroup per matrix as in the direct form (a workgroup beyond the list's
+    // length reads the count and leaves), otherwise 30 matrices per wave, each behind a dependent load of its index
+    if (in_list && !expect_many) cap = 256u * 12u;
     const unsigned grid = (unsigned)(batch < cap ? batch : cap);
     const unsigned b = (unsigned)batch;
 #define TP_LAUNCH(NT_)                                                                                                 \
@@ -505,9 +508,9 @@ static hipError_t launch_tilep(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 template <class T>
 static hipError_t launch_tilep_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count,
                                         const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                        hint_t *hint_out)
+                                        hint_t *hint_out, bool expect_many = false)
 {
-    hipError_t e = enqueue_tilep<T>(n, A, X, batch, info, stream, in_count, in_list, hint_out, bad_count, bad_list);
+    hipError_t e = enqueue_tilep<T>(n, A, X, batch, info, stream, in_count, in_list, hint_out, bad_count, bad_list, expect_many);
     if (e == hipSuccess) e = launch_gj_row_worklist<T>(n, A, X, bad_count, bad_list, info, stream);
     if (e == hipSuccess) e = debug_note_rejects(in_count, stream);
     return e;

@@ -21,6 +21,7 @@ for n in map(int, sys.argv[3:]):
         kernel_n = kernel
     for _ in range(3):
         api.inverse_batched(a, n, algo, out=x, batch=batch, kernel=kernel_n)
+    torch.cuda.synchronize()  # (a caller that has seen one batch complete: the launcher's reject-rate hint of that size class is in)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
     for s, e in ev:
         s.record(); api.inverse_batched(a, n, algo, out=x, batch=batch, kernel=kernel_n); e.record()
