@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 PKG = "cuda-matrix-inversion_amd"
 
 F64_MFMA_PEAK_TFLOPS = 78.6  # 1024 SIMDs x 32 flop/clk (v_mfma_f64_16x16x4_f64: 2048 flop per 64-cycle issue) x 2.4 GHz
+F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32: 2048 flop per 32-cycle issue, same table of the guide (fp32 matrix, dense)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 HBM_GUIDE_ACHIEVABLE_GBS = 6290.0  # same table: "6.29 TB/s measured (float4 copy, 79 %)" -- reported beside the nominal fraction
 
@@ -56,21 +57,27 @@ WORKLOADS = {
     "gj1024g": (1024, "gj", "batch x 1024x1024 fp64 blocked Gauss-Jordan (two-level, MFMA update), GENERAL U(0,1) inputs"),
     "chol256": (256, "chol", "batch x 256x256 fp64 blocked Cholesky inverse, SPD inputs"),
     "chol1024": (1024, "chol", "batch x 1024x1024 fp64 blocked Cholesky inverse (panel pairs, rank-128 update, Y Y^T product), SPD inputs"),
+    # fp32 = the reference's own DataType (include/types.h:4 there; report.tex:91 "all calculations in single precision")
+    "gj64_f32": (64, "gj", "batch x 64x64 fp32 Gauss-Jordan, SPD inputs"),
+    "chol64_f32": (64, "chol", "batch x 64x64 fp32 Cholesky inverse, SPD inputs"),
+    "gj128_f32": (128, "gj", "batch x 128x128 fp32 Gauss-Jordan, SPD inputs"),
+    "gj64g_f32": (64, "gj", "batch x 64x64 fp32 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
 }
-GENERAL = {"gj64g", "gj32g", "gj96g", "gj128g", "gj192g", "gj256g", "gj1024g"}
+GENERAL = {"gj64g", "gj32g", "gj96g", "gj128g", "gj192g", "gj256g", "gj1024g", "gj64g_f32"}
+F32 = {"gj64_f32", "chol64_f32", "gj128_f32", "gj64g_f32"}
 
 
-def make_spd(n, batch, seed, device):
+def make_spd(n, batch, seed, device, dtype=torch.float64):
     g = torch.Generator(device=device).manual_seed(seed)
-    r = torch.rand((batch, n, n), generator=g, dtype=torch.float64, device=device)
+    r = torch.rand((batch, n, n), generator=g, dtype=dtype, device=device)
     a = r + r.transpose(1, 2)
     a.diagonal(dim1=1, dim2=2).add_(float(n))
     return a.reshape(-1).contiguous()
 
 
-def make_general(n, batch, seed, device):
+def make_general(n, batch, seed, device, dtype=torch.float64):
     g = torch.Generator(device=device).manual_seed(seed)
-    return torch.rand((batch * n * n,), generator=g, dtype=torch.float64, device=device)
+    return torch.rand((batch * n * n,), generator=g, dtype=dtype, device=device)
 
 
 def usable_cores():
@@ -307,10 +314,10 @@ def mfma_flops_per_inversion(algo_name, n):
     return steps * tiles * 2048
 
 
-def rooflines(algo_name, n, batch, kern_ms):
-    """(binding roofline dict, the other one or None): HBM at 2 n^2 sizeof(T) algorithmic bytes per inversion, fp64 MFMA at
-    the flops above; the binding one is the one with the larger minimum time."""
-    bytes_per_inv = 2 * n * n * 8  # read A once + write A^-1 once (SURVEY.md 8d)
+def rooflines(algo_name, n, batch, kern_ms, elem=8):
+    """(binding roofline dict, the other one or None): HBM at 2 n^2 sizeof(T) algorithmic bytes per inversion, the MFMA pipe of the
+    data type at the flops above; the binding one is the one with the larger minimum time."""
+    bytes_per_inv = 2 * n * n * elem  # read A once + write A^-1 once (SURVEY.md 8d)
     gbs = batch * bytes_per_inv / (kern_ms * 1e-3) / 1e9
     hbm = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": batch * bytes_per_inv}
@@ -318,8 +325,8 @@ def rooflines(algo_name, n, batch, kern_ms):
     if fl is None:
         return hbm, None
     tf = batch * fl / (kern_ms * 1e-3) / 1e12
-    mf = {"bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
-          "algorithmic_flops_per_launch": batch * fl}
+    peak = F64_MFMA_PEAK_TFLOPS if elem == 8 else F32_MFMA_PEAK_TFLOPS
+    mf = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "algorithmic_flops_per_launch": batch * fl}
     if algo_name == "gj" and 192 < n < 384:
         mf["pipe"] = "fp64 vector ALU (same peak as the matrix cores on gfx950)"
     return (hbm, mf) if hbm["frac"] >= mf["frac"] else (mf, hbm)
@@ -466,12 +473,17 @@ def main():
         dist.all_reduce(ones)  # through the data-path backend (RCCL): how many ranks really took part
         ranks_seen = int(ones.item())
         if not args.no_gather:
+            # result reassembly on every rank (ONE RCCL all-gather over xGMI); host staging only in the gloo rehearsal. On the nccl
+            # backend through the C ABI (matinv_allgather_shards on the library's own RCCL communicator; MATINV_GATHER=torch:
+            # torch.distributed instead). The communicator is created and one small gather run BEFORE the timed one, so that the
+            # figure is the collective, not the unique-id broadcast + ncclCommInitRank
+            gimpl = os.environ.get("MATINV_GATHER", "c") if backend == "nccl" else "torch"
+            tiny = torch.zeros(world * shard.packing_multiple(n) * n * n, dtype=x.dtype, device=x.device if backend == "nccl" else "cpu")
+            shard.all_gather_shards(tiny[: shard.packing_multiple(n) * n * n], n, world * shard.packing_multiple(n), impl=gimpl)
+            del tiny
             torch.cuda.synchronize()
             dist.barrier()
             g0 = time.perf_counter()
-            # result reassembly on every rank (ONE RCCL all-gather over xGMI); host staging only in the gloo rehearsal.
-            # MATINV_GATHER=c: through the C ABI (matinv_allgather_shards on the library's own RCCL communicator)
-            gimpl = os.environ.get("MATINV_GATHER", "torch") if backend == "nccl" else "torch"
             full = shard.all_gather_shards(x if backend == "nccl" else x.cpu(), n, total_batch, impl=gimpl)
             torch.cuda.synchronize()
             gms = (time.perf_counter() - g0) * 1e3
@@ -516,7 +528,9 @@ def main():
             n2, algo2_name, _ = WORKLOADS[wname]
             algo2 = api.ALGO_GAUSS_JORDAN if algo2_name == "gj" else api.ALGO_CHOLESKY
             gen2 = wname in GENERAL
-            a2 = (make_general if gen2 else make_spd)(n2, b2, 0x5EED + 17 * n2, device)
+            f32 = wname in F32
+            dt2 = torch.float32 if f32 else torch.float64
+            a2 = (make_general if gen2 else make_spd)(n2, b2, 0x5EED + 17 * n2, device, dt2)
             x2 = torch.empty_like(a2)
             i2 = torch.empty(b2, dtype=torch.int32, device=device)
             # general input: the caller asks for partial pivoting (MATINV_KERNEL_TILEP; what the reference's inverse_lu_cuda_batched_*
@@ -526,13 +540,13 @@ def main():
             for _ in range(3):
                 api.inverse_batched(a2, n2, algo2, out=x2, info=i2, batch=b2, kernel=k2)
             ms2 = float(np.mean(time_launches(lambda: api.inverse_batched(a2, n2, algo2, out=x2, batch=b2, kernel=k2), reps)))
-            r1, r2 = rooflines(algo2_name, n2, b2, ms2)
-            kname2 = api.kernel_name(algo2, api.F64, n2, k2)
+            r1, r2 = rooflines(algo2_name, n2, b2, ms2, 4 if f32 else 8)
+            kname2 = api.kernel_name(algo2, api.F32 if f32 else api.F64, n2, k2)
             res2 = residual(a2, x2, n2, b2)
             # general U(0,1) matrices have condition numbers of 1e3 .. 1e6 at these sizes: the residual bound scales with it
-            tol2 = (1e-7 if gen2 else 1e-11) * n2
+            tol2 = ((2e-1 if gen2 else 1e-4) if f32 else (1e-7 if gen2 else 1e-11)) * n2
             assert res2 < tol2, f"{wname}: residual {res2} >= {tol2}"
-            d = {"kernel": kname2, "batch": b2, "kernel_ms": ms2, "input": "general U(0,1)" if gen2 else "SPD",
+            d = {"kernel": kname2, "dtype": "f32" if f32 else "f64", "batch": b2, "kernel_ms": ms2, "input": "general U(0,1)" if gen2 else "SPD",
                  "inversions_per_s": b2 / (ms2 * 1e-3), "bound": r1["bound"], "frac": r1["frac"],
                  "achieved": r1["achieved"], "unit": r1["unit"],
                  "other_bound_frac": None if r2 is None else r2["frac"], "singular_reported": int((i2 != 0).sum()),
@@ -541,7 +555,7 @@ def main():
             return d
 
         for wname in ("gj16", "chol64", "gj32", "gj24", "gj50", "gj8", "gj128", "gj64g", "gj32g", "gj96g", "gj128g", "gj192g", "chol192", "gj256g", "chol256",
-                      "gj1024g", "chol1024"):
+                      "gj1024g", "chol1024", "gj64_f32", "chol64_f32", "gj128_f32", "gj64g_f32"):
             if wname == args.workload:
                 continue
             n2 = WORKLOADS[wname][0]
@@ -574,6 +588,21 @@ def main():
                       "ms": t_e * 1e3, "inversions_per_s": b_e / t_e, "host_link_GBs_both_directions": 2 * ha.nbytes / t_e / 1e9,
                       "host_link_spec_GBs_per_direction": 63.0, "devices": int(os.environ.get("MATINV_DEVICES", "1")),
                       "residual_last_matrix": float(he), "calls_timed": len(ts)}
+        ndev_e = api.device_count()
+        if ndev_e > 1:
+            # the same batch block-partitioned over every device of the node, one host thread and one host link per device
+            # (matinv_inverse_batched_host_multi; what MATINV_DEVICES=N gives the reference-named entry points)
+            api.inverse_batched_host_multi(ha, n_e, api.ALGO_GAUSS_JORDAN, nshards=ndev_e)
+            tm = []
+            for _ in range(3):
+                t_ = time.perf_counter()
+                hx_m, _info_m = api.inverse_batched_host_multi(ha, n_e, api.ALGO_GAUSS_JORDAN, nshards=ndev_e)
+                tm.append(time.perf_counter() - t_)
+            t_m = float(np.median(tm))
+            end_to_end["all_devices"] = {"call": f"matinv_inverse_batched_host_multi(..., nshards={ndev_e})", "devices": ndev_e, "ms": t_m * 1e3,
+                                         "inversions_per_s": b_e / t_m, "host_link_GBs_both_directions": 2 * ha.nbytes / t_m / 1e9,
+                                         "same_bits_as_one_device": bool(np.array_equal(np.asarray(hx_m).reshape(-1), hx))}
+            del hx_m
         del ha, hx
 
         # BASELINE configs[4] on this GPU (the C queue), a short run of the same code path as --workload mixed
@@ -610,6 +639,8 @@ def main():
             out["gather"] = gather
             if "allgather_ms" in gather:
                 out["allgather_ms"] = gather["allgather_ms"]
+                # the inversions of one step followed by the reassembly of their results on every rank (never `value`)
+                out["value_with_gather"] = total_batch / (elapsed / args.steps + gather["allgather_ms"] * 1e-3)
         if others:
             out["other_workloads"] = others
         if end_to_end is not None:

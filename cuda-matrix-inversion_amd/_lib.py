@@ -37,7 +37,7 @@ NATIVE_NAMES = [
     "matinv_device_synchronize", "matinv_tile_stats", "matinv_queue_create", "matinv_queue_submit", "matinv_queue_submit_chunks", "matinv_queue_pending",
     "matinv_queue_bins", "matinv_queue_flush", "matinv_queue_destroy", "matinv_queue_last_error",
     "matinv_set_gj_policy", "matinv_device_count", "matinv_shard_range", "matinv_inverse_batched_host_multi", "matinv_comm_unique_id",
-    "matinv_comm_init_rank", "matinv_comm_destroy", "matinv_allgather_shards", "matinv_allgather_local", "matinv_debug_rejects",
+    "matinv_comm_init_rank", "matinv_comm_destroy", "matinv_allgather_shards", "matinv_allgather_local", "matinv_allgather_local_after", "matinv_debug_rejects",
 ]
 GJ_NATURAL_FIRST, GJ_PIVOT, GJ_ADAPTIVE = 0, 1, 2
 
@@ -102,6 +102,8 @@ def lib() -> ctypes.CDLL:
     L.matinv_allgather_shards.argtypes = [vp, ci, vp, vp, sz, vp]
     L.matinv_allgather_local.restype = ci
     L.matinv_allgather_local.argtypes = [ci, vp, ci, vp, vp, sz]
+    L.matinv_allgather_local_after.restype = ci
+    L.matinv_allgather_local_after.argtypes = [ci, vp, ci, vp, vp, sz, vp]
     L.matinv_tile_stats.restype = ci
     L.matinv_tile_stats.argtypes = [vp, vp, vp, vp]
     L.matinv_batched_malloc.restype = ci

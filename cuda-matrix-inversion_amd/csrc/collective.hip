@@ -161,8 +161,13 @@ int matinv_allgather_shards(void *comm, int dtype, const void *dSend, void *dRec
 }
 
 // single process, ndev devices: dSend[g] (count elements on devices[g]) gathered into dRecv[g] (ndev * count elements on
-// devices[g]) for every g; returns when all of it has completed
-int matinv_allgather_local(int ndev, const int *devices, int dtype, const void *const *dSend, void *const *dRecv, size_t count)
+// devices[g]) for every g; returns when all of it has completed. The gather runs on the library's own streams: it is ordered
+// behind the work that produces dSend[g] through `producers` -- producers[g] = the stream (on devices[g]) whose work so far writes
+// dSend[g]: an event recorded there is waited for on the gather's stream (a null entry = the device's null stream). With
+// producers == nullptr every device is synchronised on entry instead (r03 took neither precaution: a caller that inverted
+// asynchronously and gathered at once could have shipped a half-written shard -- ADVICE r03).
+static int allgather_local_impl(int ndev, const int *devices, int dtype, const void *const *dSend, void *const *dRecv, size_t count,
+                                void *const *producers)
 {
     if (ndev < 1 || !devices || !dSend || !dRecv) return fail(MATINV_ERR_ARG, "matinv_allgather_local: bad argument");
     Rccl *r;
@@ -180,26 +185,50 @@ int matinv_allgather_local(int ndev, const int *devices, int dtype, const void *
     if (!lc) {
         LocalComms c;
         c.devices.assign(devices, devices + ndev);
-        c.comms.resize(ndev);
-        c.streams.resize(ndev);
+        c.comms.assign(ndev, nullptr);
+        c.streams.assign(ndev, nullptr);
         ncclResult_t e = r->CommInitAll(c.comms.data(), ndev, devices);
         if (e) return fail_nccl(r, e, "ncclCommInitAll");
-        for (int g = 0; g < ndev; ++g) {
-            hipError_t he = hipSetDevice(devices[g]);
+        hipError_t he = hipSuccess;
+        for (int g = 0; g < ndev && he == hipSuccess; ++g) {
+            he = hipSetDevice(devices[g]);
             if (he == hipSuccess) he = hipStreamCreateWithFlags(&c.streams[g], hipStreamNonBlocking);
-            if (he != hipSuccess) {
-                (void)hipSetDevice(home);
-                return fail_hip(he, "stream for the all-gather");
+        }
+        if (he != hipSuccess) {
+            // nothing half-built stays behind: the streams created so far and the communicators go
+            for (int g = 0; g < ndev; ++g) {
+                if (c.streams[g] && hipSetDevice(devices[g]) == hipSuccess) (void)hipStreamDestroy(c.streams[g]);
+                if (c.comms[g]) (void)r->CommDestroy(c.comms[g]);
             }
+            (void)hipSetDevice(home);
+            return fail_hip(he, "stream for the all-gather");
         }
         g_local.push_back(c);
         lc = &g_local.back();
+    }
+    // order the gather behind the producers of the shards
+    hipError_t he = hipSuccess;
+    for (int g = 0; g < ndev && he == hipSuccess; ++g) {
+        he = hipSetDevice(devices[g]);
+        if (he != hipSuccess) break;
+        if (!producers) {
+            he = hipDeviceSynchronize();
+        } else {
+            hipEvent_t ev = nullptr;
+            he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventRecord(ev, static_cast<hipStream_t>(producers[g]));
+            if (he == hipSuccess) he = hipStreamWaitEvent(lc->streams[g], ev, 0);
+            if (ev) (void)hipEventDestroy(ev);  // deferred by the runtime until the recorded work has completed
+        }
+    }
+    if (he != hipSuccess) {
+        (void)hipSetDevice(home);
+        return fail_hip(he, "ordering the all-gather behind its producers");
     }
     ncclResult_t e = r->GroupStart();
     for (int g = 0; g < ndev && !e; ++g) e = r->AllGather(dSend[g], dRecv[g], count, t, lc->comms[g], lc->streams[g]);
     ncclResult_t e2 = r->GroupEnd();
     if (!e) e = e2;
-    hipError_t he = hipSuccess;
     for (int g = 0; g < ndev; ++g) {
         hipError_t h1 = hipSetDevice(devices[g]);
         if (h1 == hipSuccess) h1 = hipStreamSynchronize(lc->streams[g]);
@@ -209,6 +238,18 @@ int matinv_allgather_local(int ndev, const int *devices, int dtype, const void *
     if (e) return fail_nccl(r, e, "ncclAllGather (group)");
     if (he != hipSuccess) return fail_hip(he, "all-gather completion");
     return MATINV_OK;
+}
+
+int matinv_allgather_local(int ndev, const int *devices, int dtype, const void *const *dSend, void *const *dRecv, size_t count)
+{
+    return allgather_local_impl(ndev, devices, dtype, dSend, dRecv, count, nullptr);
+}
+
+int matinv_allgather_local_after(int ndev, const int *devices, int dtype, const void *const *dSend, void *const *dRecv, size_t count,
+                                 void *const *producer_streams)
+{
+    if (!producer_streams) return fail(MATINV_ERR_ARG, "matinv_allgather_local_after: null producer stream array");
+    return allgather_local_impl(ndev, devices, dtype, dSend, dRecv, count, producer_streams);
 }
 
 }  // extern "C"

@@ -1,5 +1,8 @@
-// spd_tile2_impl.hpp (instantiated by spd_tile2_kernels.hip, fp64) -- the symmetric blocked sweep of matinv_spd_tile_f64
-// (tile_kernels.inc: read its header first) for 112 < n <= 128 on TWO wavefronts per matrix, LOWER tiles only. r03.
+// spd_tile2_impl.hpp (instantiated by spd_tile2_kernels.hip and spd_tile2_wide*_kernels.hip, fp64) -- the symmetric blocked sweep of
+// matinv_spd_tile_f64 (tile_kernels.inc: read its header first) on TWO wavefronts per matrix, LOWER tiles only: 112 < n <= 128
+// (8 x 8 tiles, r03) and -- r04 -- 128 < n <= 176 (9 ... 11 tiles per dimension: 23 ... 33 lower tiles = up to 288 accumulator registers
+// per wave, so these run ONE wave per SIMD on VGPRs + AGPRs, two matrices per CU; before, these sizes swept ALL n^2 tiles with one
+// wavefront per tile column and one matrix per CU: 130^2 Cholesky 3.4e6 inv/s, a 2.9 x cliff behind 128^2).
 //
 // 8 x 8 tiles keep 36 lower tiles = 288 fp64 registers: 32 more than the AGPR file, so the one-wavefront form that serves n <= 112
 // spills, and r01 / r02 ran these sizes on four wavefronts that sweep ALL 64 tiles (tile4_impl.hpp: the B operand there is a
@@ -32,7 +35,9 @@ struct Spd2Gp {
     T *out;
 };
 
-// tile column of local column jl of wave w, and its inverse
+// tile column of local column jl of wave w (folded: 0 1 | 1 0 | 0 1 | ... so that both waves hold the same number of lower tiles
+// +- 1), and its inverse. Local column jl exists from tile row 2 jl on.
+constexpr int spd2_col_c(int w, int jl) { return (jl & 1) ? (4 * (jl >> 1) + 3 - w) : (4 * (jl >> 1) + w); }
 __device__ __forceinline__ int spd2_col(int w, int jl) { return (jl & 1) ? (4 * (jl >> 1) + 3 - w) : (4 * (jl >> 1) + w); }
 constexpr int spd2_owner(int tj) { return ((tj + 1) >> 1) & 1; }
 constexpr int spd2_local(int tj) { return tj >> 1; }
@@ -52,14 +57,18 @@ struct Spd2Steps {
     }
 };
 
-template <bool GP>
+// SELF: no Cholesky kernel behind this one serves every such n (the LDS kernel stops at n = 137), so an item that is not positive
+// definite is finished here: info = the column of the first non-positive pivot + 1 (the Cholesky contract), output NaN-filled.
+template <int NT, bool GP>
 __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt, unsigned batch,
                                                int *work_count, int *work_list, double *panel2, double *tbuf2, Spd2Gp<double> gp)
 {
     typedef double T;
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
-    constexpr int NT = 8, N = 16 * NT, NKB = 4 * NT, NL = 4;
+    static_assert(NT >= 8 && NT <= 12, "two wavefronts: 8 ... 12 tiles per dimension");
+    constexpr int N = 16 * NT, NKB = 4 * NT, NL = (NT + 1) / 2;
+    constexpr bool SELF = NT > 8;
     constexpr int TSTRIDE = 17;  // padded row stride of the 16 x 16 transpose buffers (one per wave)
     const int l = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;  // wave-uniform: 0 or 1
@@ -76,7 +85,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
         int q = l >> 4, c = l & 15;
         asm volatile("" : "+v"(q), "+v"(c));
 
-        // acc[jl][ti] = tile (ti, tjs[jl]) of W = A^T (symmetric); slots ti = 2 jl .. 7; a slot with ti < tjs[jl] is not owned
+        // acc[jl][ti] = tile (ti, tjs[jl]) of W = A^T (symmetric); slots ti = 2 jl .. NT - 1; a slot with ti < tjs[jl] is not owned
         vec4 acc[NL][NT];
 #pragma unroll
         for (int jl = 0; jl < NL; ++jl) {
@@ -95,6 +104,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
                 }
         }
         unsigned long long bad = 0;
+        int badinfo = 0;
 
         // panel of block kb into buffer kb & 1: rows >= 16 tK from the tiles of column tK (its owner), rows < 16 tK from the
         // pivot rows of tile row tK, each wave the columns it owns (W[16 ti + c][pivot q] = W[pivot q][16 ti + c])
@@ -119,7 +129,10 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
         stage(IntC2<0>());
         __syncthreads();
         const int last_blocks = G::real_blocks(n - 16 * (NT - 1));
-
+        // (r04, measured and not kept: the look-ahead of the one-wavefront sweep -- the slots the next panel is read from updated first, the
+        // next panel staged and solved between the remaining MFMAs. With the second operand set the 9 x 9 kernel needs 460 registers
+        // instead of 368 and the 10 x 10 / 11 x 11 ones spill or crash hipcc's "Rewrite AGPR-Copy-MFMA" pass; where it compiles it is
+        // SLOWER: Cholesky 130^2 6.0e6 -> 5.6e6 inv/s, 160^2 4.3e6 -> 3.2e6; at 8 x 8 tiles, two waves per SIMD, 1 413 registers spill.)
         auto step = [&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
             constexpr int tK = kb >> 2, rK = kb & 3, jo = spd2_local(tK);
@@ -128,14 +141,17 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
             const T *const buf = panel2 + (kb & 1) * (N * 4);
             T aop[NT], bsym[NT];
             PanelSolve<NT, true, T> ps;
+            if (SELF) ps.binfo = &badinfo;
 #pragma unroll
             for (int s = 0; s < PanelSolve<NT, true, T>::NSTAGE; ++s) ps.stage(s, buf, kb, q, c, aop, bsym, bad);
             // B operand of the wave's columns: the old panel by symmetry; -I_4 on the pivot columns (their owner)
             T bop[NL];
-            bop[0] = w ? bsym[1] : bsym[0];
-            bop[1] = w ? bsym[2] : bsym[3];
-            bop[2] = w ? bsym[5] : bsym[4];
-            bop[3] = w ? bsym[6] : bsym[7];
+#pragma unroll
+            for (int jl = 0; jl < NL; ++jl) {
+                const int t0 = spd2_col_c(0, jl), t1 = spd2_col_c(1, jl);  // fold to literals after unrolling
+                const T b0 = t0 < NT ? bsym[t0 < NT ? t0 : 0] : (T)0, b1 = t1 < NT ? bsym[t1 < NT ? t1 : 0] : (T)0;
+                bop[jl] = w ? b1 : b0;
+            }
             const bool panel_lane = (w == spd2_owner(tK)) && G::blk(c) == rK;
             const bool diag_lane = panel_lane && (G::piv(c) == q);
             bop[jo] = panel_lane ? (diag_lane ? (T)-1 : (T)0) : bop[jo];
@@ -164,8 +180,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
             const T *va = gp.a + (size_t)mat * n;
             const T *vd = gp.d ? gp.d + (size_t)mat * n : va;
             T *const sa = panel2, *const sd = panel2 + N, *const part = panel2 + 2 * N;  // both panel buffers are free now
-            {
-                const int i = threadIdx.x;  // 128 threads, N = 128
+            for (int i = threadIdx.x; i < N; i += 128) {
                 sa[i] = i < n ? va[i] : (T)0;
                 sd[i] = i < n ? vd[i] : (T)0;
             }
@@ -198,6 +213,9 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
                     const T sum = part[0] + part[1];
                     gp.out[mat] = gp.d ? -sum : gp.e[mat] + sum;
                     if (info) info[mat] = 0;
+                } else if (SELF) {
+                    gp.out[mat] = nan_of<T>();
+                    if (info) info[mat] = badinfo;
                 } else {
                     const int slot = atomicAdd(work_count, 1);  // not SPD: the LDS pipeline kernel reports the column
                     work_list[slot] = (int)mat;
@@ -232,6 +250,9 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
                 }
             }
             if (info && threadIdx.x == 0) info[mat] = 0;
+        } else if (SELF) {
+            for (unsigned e = threadIdx.x; e < (unsigned)(n * n); e += 128u) X[e] = nan_of<T>();  // (a plain strided fill: see gj_tile4_body)
+            if (info && threadIdx.x == 0) info[mat] = badinfo;
         } else if (threadIdx.x == 0) {
             const int slot = atomicAdd(work_count, 1);  // not SPD: the LDS Cholesky kernel reports the column
             work_list[slot] = (int)mat;
@@ -246,7 +267,28 @@ __global__ __launch_bounds__(128, 2) void matinv_spd_tile2_f64(BatchRef<const do
 {
     __shared__ __attribute__((aligned(16))) double panel2[2 * 128 * 4];  // double buffered [row][4 pivot columns]
     __shared__ __attribute__((aligned(16))) double tbuf2[2 * 16 * 17];   // one padded 16 x 16 transpose buffer per wave
-    spd_tile2_body<GP>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel2, tbuf2, gp);
+    spd_tile2_body<8, GP>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel2, tbuf2, gp);
 }
+
+// 9 ... 12 tiles per dimension: one wave per SIMD (VGPRs + AGPRs), two matrices per CU
+template <int NT, bool GP>
+__global__ __launch_bounds__(128, 1) void matinv_spd_tile2w_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
+                                                               unsigned batch, int *work_count, int *work_list, Spd2Gp<double> gp)
+{
+    __shared__ __attribute__((aligned(16))) double panel2[2 * 16 * NT * 4];
+    __shared__ __attribute__((aligned(16))) double tbuf2[2 * 16 * 17];
+    spd_tile2_body<NT, GP>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel2, tbuf2, gp);
+}
+
+// the launch of the NT x NT-tile kernel (NT = 9 ... 11), defined in spd_tile2w<NT>_kernels.hip
+template <int NT>
+hipError_t enqueue_spd_tile2w(bool gp_mode, int n, BatchRef<const double> A, BatchRef<double> X, unsigned grid, unsigned batch, int *info,
+                              int *ws, Spd2Gp<double> gp, hipStream_t stream);
+template <>
+hipError_t enqueue_spd_tile2w<9>(bool, int, BatchRef<const double>, BatchRef<double>, unsigned, unsigned, int *, int *, Spd2Gp<double>, hipStream_t);
+template <>
+hipError_t enqueue_spd_tile2w<10>(bool, int, BatchRef<const double>, BatchRef<double>, unsigned, unsigned, int *, int *, Spd2Gp<double>, hipStream_t);
+template <>
+hipError_t enqueue_spd_tile2w<11>(bool, int, BatchRef<const double>, BatchRef<double>, unsigned, unsigned, int *, int *, Spd2Gp<double>, hipStream_t);
 
 }  // namespace matinv

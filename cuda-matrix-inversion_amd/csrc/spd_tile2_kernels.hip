@@ -1,37 +1,51 @@
-// spd_tile2_kernels.hip -- the two-wavefront lower-triangle SPD sweep for 112 < n <= 128, fp64 (spd_tile2_impl.hpp): Cholesky
-// entry point and fused mean / variance.
+// spd_tile2_kernels.hip -- the two-wavefront lower-triangle SPD sweep, fp64 (spd_tile2_impl.hpp): Cholesky entry point and fused
+// mean / variance for 112 < n <= 128 (8 x 8 tiles, instantiated here) and 128 < n <= 176 (9 ... 11 tiles per dimension: one translation
+// unit per tile count, spd_tile2w{9,10,11}_kernels.hip, so that the fully unrolled sweeps compile in parallel). 12 x 12 tiles (39 + 3
+// accumulator tiles per wave = 336 registers, + 24 for the A operand) do not fit 512 registers: hipcc spills 324 of them with AGPR-form
+// MFMAs and crashes in its "Rewrite AGPR-Copy-MFMA" pass with VGPR-form ones (ROCm 7.2.0) -- 176 < n <= 192 stays on the kernel with one
+// wavefront per tile column (tile4_impl.hpp).
 #include "spd_tile2_impl.hpp"
 
 namespace matinv {
 
-// MATINV_SPD_TILE2=0: these sizes stay on the four-wavefront kernel that sweeps all tiles (A/B switch)
+// MATINV_SPD_TILE2=0: these sizes stay on the kernels that sweep all tiles (four wavefronts per matrix up to n = 128, one per tile
+// column beyond) -- A/B switch
 bool spd_tile2_supports(bool f64, int n)
 {
     static const bool on = [] { const char *s = getenv("MATINV_SPD_TILE2"); return !(s && *s == '0'); }();
-    return on && f64 && n > 112 && n <= 128;
+    return on && f64 && n > 112 && n <= 176;
 }
 
 template <bool GP>
 static hipError_t launch_tile2(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream, int *ws,
                                Spd2Gp<double> gp)
 {
-    const unsigned resident = 256u * 4u;  // four workgroups of two waves per CU
+    const int nt = (n + 15) / 16;
+    // n <= 128: four workgroups of two waves per CU; beyond: one wave per SIMD (VGPRs + AGPRs), two workgroups per CU
+    const unsigned resident = nt <= 8 ? 256u * 4u : 256u * 2u;
     const unsigned cap = resident * tile_grid_rounds();
     const unsigned grid = (unsigned)(batch < cap ? batch : cap);
-    hipLaunchKernelGGL((matinv_spd_tile2_f64<GP>), dim3(grid), dim3(128), 0, stream, A, X, info, n, (unsigned)batch, ws, ws + 1, gp);
+    switch (nt) {
+    case 8: hipLaunchKernelGGL((matinv_spd_tile2_f64<GP>), dim3(grid), dim3(128), 0, stream, A, X, info, n, (unsigned)batch, ws, ws + 1, gp); break;
+    case 9: return enqueue_spd_tile2w<9>(GP, n, A, X, grid, (unsigned)batch, info, ws, gp, stream);
+    case 10: return enqueue_spd_tile2w<10>(GP, n, A, X, grid, (unsigned)batch, info, ws, gp, stream);
+    case 11: return enqueue_spd_tile2w<11>(GP, n, A, X, grid, (unsigned)batch, info, ws, gp, stream);
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_spd_tile2(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream)
 {
-    if (n <= 112 || n > 128) return hipErrorInvalidValue;
+    if (n <= 112 || n > 176) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, sizeof(int), stream);
     if (e == hipSuccess) e = launch_tile2<false>(n, A, X, batch, info, stream, ws, Spd2Gp<double>());
-    if (e == hipSuccess) e = launch_chol_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream);
+    // n <= 128: items that are not positive definite go to the LDS Cholesky (it reports the column); beyond, the kernel finishes them
+    if (e == hipSuccess && n <= 128) e = launch_chol_lds_worklist<double>(n, A, X, ws, ws + 1, info, stream);
     hipError_t e2 = scratch_free(ws, stream);
     return e != hipSuccess ? e : e2;
 }
@@ -39,7 +53,7 @@ hipError_t launch_spd_tile2(int n, BatchRef<const double> A, BatchRef<double> X,
 hipError_t launch_gp_spd_tile2(int n, const double *As, const double *Bs, const double *Cs, const double *Ds, const double *Es, double *out,
                                size_t batch, int *info, hipStream_t stream)
 {
-    if (n <= 112 || n > 128) return hipErrorInvalidValue;
+    if (n <= 112 || n > 176) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     int *ws = nullptr;
     hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
@@ -48,11 +62,17 @@ hipError_t launch_gp_spd_tile2(int n, const double *As, const double *Bs, const 
     BatchRef<const double> A{Bs, (size_t)n * n, nullptr};
     BatchRef<double> X{nullptr, 0, nullptr};
     if (e == hipSuccess) e = launch_tile2<true>(n, A, X, batch, info, stream, ws, Spd2Gp<double>{As, Cs, Ds, Es, out});
-    if (e == hipSuccess) e = launch_gp_lds_worklist<double>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
+    if (e == hipSuccess && n <= 128) e = launch_gp_lds_worklist<double>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
     hipError_t e2 = scratch_free(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 
-const char *name_spd_tile2(bool gp) { return gp ? "matinv_spd_tile2_f64<true>" : "matinv_spd_tile2_f64<false>"; }
+const char *name_spd_tile2(bool gp, int n)
+{
+    static thread_local char buf[48];
+    if (n <= 128) return gp ? "matinv_spd_tile2_f64<true>" : "matinv_spd_tile2_f64<false>";
+    snprintf(buf, sizeof buf, "matinv_spd_tile2w_f64<%d, %s>", (n + 15) / 16, gp ? "true" : "false");
+    return buf;
+}
 
 }  // namespace matinv

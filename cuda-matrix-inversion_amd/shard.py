@@ -69,13 +69,15 @@ def all_gather_shards(local, n: int, batch: int, group=None, impl: str | None = 
     """Reassemble the full result on every rank from per-rank shards (flat tensors of shard*n*n elements).
 
     Shards are padded to the common shard size so ONE fixed-size all-gather moves everything (each GPU's contiguous shard
-    goes out once over its xGMI links); the padding is sliced off afterwards. impl = "c" (or MATINV_GATHER=c): the C ABI's
-    matinv_allgather_shards (ncclAllGather on the library's own communicator, device tensors only); default
-    "torch": torch.distributed.all_gather_into_tensor on the group's backend (RCCL for "nccl"; gloo for the CPU rehearsal).
+    goes out once over its xGMI links); the padding is sliced off afterwards. impl = "c": the C ABI's matinv_allgather_shards
+    (ncclAllGather on the library's own communicator) -- the default for device tensors on the "nccl" backend since r04 (the C
+    path is the product; MATINV_GATHER=torch switches back); "torch": torch.distributed.all_gather_into_tensor on the group's
+    backend (RCCL for "nccl"; gloo for the CPU rehearsal, where it is the only choice).
     """
     import torch
     import torch.distributed as dist
-    impl = impl or os.environ.get("MATINV_GATHER", "torch")
+    if impl is None:
+        impl = os.environ.get("MATINV_GATHER") or ("c" if (local.is_cuda and dist.get_backend(group) == "nccl") else "torch")
     world = dist.get_world_size(group)
     parts = partition(batch, world, packing_multiple(n))
     per = max(hi - lo for lo, hi in parts) if parts else 0

@@ -146,12 +146,19 @@ int matinv_shard_range(size_t batch, int nshards, int n, int g, size_t *lo, size
  * contributes `count` elements (pad the short tail shard) and receives nranks * count.
  *   one process per GPU: matinv_comm_unique_id on rank 0 -> ship the 128 bytes to the others by any means ->
  *                        matinv_comm_init_rank everywhere -> matinv_allgather_shards(comm, ...) on each rank's stream;
- *   one process, several GPUs: matinv_allgather_local(ndev, devices, ...) (communicators created once and cached). */
+ *   one process, several GPUs: matinv_allgather_local(ndev, devices, ...) (communicators created once and cached). It runs on
+ *                        the library's own streams and returns when the gather has completed. Input readiness:
+ *                        matinv_allgather_local synchronises every listed device on entry (whatever was enqueued there before the
+ *                        call has finished when the gather reads dSend[g]); matinv_allgather_local_after takes, per device, the
+ *                        stream whose work so far produces dSend[g] (0 = that device's null stream) and makes the gather wait
+ *                        for an event recorded on it instead -- no host-side synchronisation of the producers. */
 int matinv_comm_unique_id(void *id128);
 int matinv_comm_init_rank(void **comm, int nranks, const void *id128, int rank);
 int matinv_comm_destroy(void *comm);
 int matinv_allgather_shards(void *comm, int dtype, const void *dSend, void *dRecv, size_t count, void *stream);
 int matinv_allgather_local(int ndev, const int *devices, int dtype, const void *const *dSend, void *const *dRecv, size_t count);
+int matinv_allgather_local_after(int ndev, const int *devices, int dtype, const void *const *dSend, void *const *dRecv, size_t count,
+                                 void *const *producer_streams);
 
 /* Host-pointer form of the fused pipeline (what gauss_bench times): H2D, one kernel, D2H of `batch` scalars.
  * Inputs are NOT modified (the reference CPU path destroys Bs and Cs, include/gauss_cpu.h:42 there). Synchronous. */

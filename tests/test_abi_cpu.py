@@ -56,6 +56,8 @@ def test_kernel_selection_is_pure_host_logic():
     # r03: one wavefront per matrix on VGPRs + AGPRs up to 7 x 7 lower tiles (fp64 Cholesky), 8 x 8 in fp32
     assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 100) == "matinv_spd_tile_f64<7, false>"
     assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 120) == "matinv_spd_tile2_f64<false>"  # two waves, lower tiles only
+    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 144) == "matinv_spd_tile2w_f64<9, false>"  # r04: the same beyond 128, one wave per SIMD
+    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 176) == "matinv_spd_tile2w_f64<11, false>"
     assert api.kernel_name(api.ALGO_CHOLESKY, api.F32, 128) == "matinv_spd_tile_f32<8, false>"
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 96) == "matinv_gj_tile4_f64<6, true, 2, false>"
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 512) == api.KERNEL_BLOCKED

@@ -80,3 +80,41 @@ def test_c_abi_allgather_single_process():
     torch.cuda.synchronize()
     assert torch.equal(send, recv)
     lib.check(L.matinv_comm_destroy(comm))
+
+
+def test_local_allgather_is_ordered_behind_its_producer_stream():
+    """matinv_allgather_local ran on the library's own streams with nothing ordering it behind the work that
+    produces the shard. matinv_allgather_local_after takes the producer stream (an event recorded there is waited for on the
+    gather's stream): a large inversion enqueued on a side stream and gathered AT ONCE, no host synchronisation in between, must
+    arrive complete; the plain form synchronises the device on entry and passes the same check."""
+    import ctypes
+    import importlib
+    import torch
+    lib = importlib.import_module("cuda-matrix-inversion_amd._lib")
+    api = importlib.import_module("cuda-matrix-inversion_amd.api")
+    L = lib.lib()
+    n, batch = 64, 20_000  # ~0.4 ms of kernel: long enough that an unordered gather would read it half-written
+    g = torch.Generator(device="cuda").manual_seed(5)
+    r = torch.rand(batch, n, n, generator=g, dtype=torch.float64, device="cuda")
+    a = (r + r.transpose(1, 2) + n * torch.eye(n, dtype=torch.float64, device="cuda")).reshape(-1).contiguous()
+    want = api.inverse_batched(a, n, api.ALGO_GAUSS_JORDAN, batch=batch).clone()
+    torch.cuda.synchronize()
+    devs = (ctypes.c_int * 1)(0)
+    side = torch.cuda.Stream()
+    for ordered in (True, False):
+        x = torch.zeros_like(a)
+        recv = torch.zeros_like(a)
+        torch.cuda.synchronize()
+        sp = (ctypes.c_void_p * 1)(x.data_ptr())
+        rp = (ctypes.c_void_p * 1)(recv.data_ptr())
+        with torch.cuda.stream(side):
+            for _ in range(3):  # a few launches deep
+                api.inverse_batched(a, n, api.ALGO_GAUSS_JORDAN, out=x, batch=batch)
+        if ordered:
+            st = (ctypes.c_void_p * 1)(side.cuda_stream)
+            lib.check(L.matinv_allgather_local_after(1, devs, lib.F64, sp, rp, x.numel(), st))
+        else:
+            lib.check(L.matinv_allgather_local(1, devs, lib.F64, sp, rp, x.numel()))
+        # the call returns when the gather has completed: recv is final without any synchronisation here
+        assert torch.equal(recv, want), "the gather read its shard before the producer had finished"
+    torch.cuda.synchronize()

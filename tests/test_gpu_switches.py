@@ -28,7 +28,7 @@ SETTINGS = [
     # one wavefront per matrix
     ({"MATINV_TILE_GRID_MULT": "1"}, ["gj_spd:f64:64:5000", "chol:f64:48:5000", "mean:f64:64:5000"]),
     ({"MATINV_ONEWAVE_WIDE": "0"}, ["chol:f64:100:30", "chol:f64:112:30", "chol:f32:150:20", "mean:f64:100:30", "mean:f32:120:30"]),
-    ({"MATINV_SPD_TILE2": "0"}, ["chol:f64:120:30", "chol:f64:128:30", "mean:f64:128:30"]),
+    ({"MATINV_SPD_TILE2": "0"}, ["chol:f64:120:30", "chol:f64:128:30", "mean:f64:128:30", "chol:f64:144:12", "mean:f64:160:12", "variance:f64:176:12"]),
     # fused mean / variance dispatch
     ({"MATINV_GP_ROWLANE": "0"}, ["mean:f64:8:100", "variance:f64:16:100", "mean:f32:12:100"]),
     ({"MATINV_GP_TILE": "0"}, ["mean:f64:32:60", "variance:f64:64:60", "mean:f32:80:40"]),
