@@ -53,6 +53,9 @@ WORKLOADS = {
     "gj128g": (128, "gj", "batch x 128x128 fp64 Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
     "gj192g": (192, "gj", "batch x 192x192 fp64 Gauss-Jordan with partial pivoting (one wavefront per tile column), GENERAL U(0,1) inputs"),
     "chol192": (192, "chol", "batch x 192x192 fp64 Cholesky inverse (one wavefront per tile column), SPD inputs"),
+    "chol130": (130, "chol", "batch x 130x130 fp64 Cholesky inverse (two wavefronts, lower tiles only, one wave per SIMD), SPD inputs"),
+    "chol144": (144, "chol", "batch x 144x144 fp64 Cholesky inverse (two wavefronts, lower tiles only, one wave per SIMD), SPD inputs"),
+    "chol128": (128, "chol", "batch x 128x128 fp64 Cholesky inverse (two wavefronts, lower tiles only), SPD inputs"),
     "gj256g": (256, "gj", "batch x 256x256 fp64 blocked Gauss-Jordan with partial pivoting, GENERAL U(0,1) inputs"),
     "gj1024g": (1024, "gj", "batch x 1024x1024 fp64 blocked Gauss-Jordan (two-level, MFMA update), GENERAL U(0,1) inputs"),
     "chol256": (256, "chol", "batch x 256x256 fp64 blocked Cholesky inverse, SPD inputs"),
@@ -169,13 +172,11 @@ def mixed_result(args, api, device, rank, world):
     # many queues, each on its own stream, so the dependent-launch chain of one step's large bins (8 x 1024^2 = 34 launches that
     # leave most of the chip idle) runs beside the next step's. Every step still submits and flushes ALL of its items, results
     # are complete at the synchronisation that ends the timed region; 1 = strictly one flush after the other (the r01/r02 figure).
-    # Stream placement: HIP binds a stream to one of the four hardware queues at its first use, round-robin, and two launch
-    # chains that share a hardware queue do not overlap (measured: 0.73 to 1.44 ms per step for the same work, depending only on
-    # how many streams the process had used before). With more than one flush in flight the leg therefore builds a few stream
-    # sets (one more used dummy stream before each), times six steps on each and keeps the set whose chains overlap best.
+    # Stream placement (r04): a queue binds its two chain streams to consecutive hardware queues when it is created
+    # (matinv_queue_create), so the queues built here -- one right after the other -- put their four chains on four different
+    # hardware queues whatever the process did before. r03 left the binding to the first flush and got 0.72 or 0.95 ms per step
+    # depending on how many streams had been used before; it tried four stream sets and reported the best. No selection any more.
     inflight = max(1, int(os.environ.get("MATINV_MIX_INFLIGHT", str(getattr(args, "inflight", 2)))))
-    keep_alive = []
-
     def make_set():
         qs_ = [bq.SizeBinnedQueue(device=device) for _ in range(inflight)]
         st_ = [torch.cuda.Stream(device=device) for _ in range(inflight)] if inflight > 1 else [torch.cuda.current_stream(device)]
@@ -195,31 +196,7 @@ def mixed_result(args, api, device, rank, world):
         host_s[0] += time.perf_counter() - t_  # submit + flush return when everything is ENQUEUED: the host share of a step
         return out
 
-    def short_run(k):
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t_ = time.perf_counter()
-        for _ in range(k):
-            step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t_) / k * 1e3
-
-    placement = None
-    if inflight > 1:
-        trials = []
-        for trial in range(int(os.environ.get("MATINV_MIX_PLACEMENTS", "4"))):
-            if trial:
-                d_ = torch.cuda.Stream(device=device)  # one more used stream shifts the round-robin
-                with torch.cuda.stream(d_):
-                    torch.zeros(1, device=device)
-                keep_alive.append(d_)
-                cur = make_set()
-            trials.append((short_run(6), cur))
-        torch.cuda.synchronize()
-        best = min(range(len(trials)), key=lambda i: trials[i][0])
-        cur = trials[best][1]
-        placement = {"stream_sets_tried": len(trials), "ms_per_step_of_each": [round(t, 3) for t, _ in trials], "kept": best}
+    placement = "bound at matinv_queue_create (consecutive hardware queues); no trials"
     q = cur["qs"][0]
 
     import torch.distributed as tdist
@@ -295,8 +272,8 @@ def run_mixed(args, api, device, rank, world):
 
 def mfma_flops_per_inversion(algo_name, n):
     """fp64 flops the MFMA tile kernels issue per matrix (None for the families without MFMA): a blocked sweep of 4*NT
-    rank-4 steps over NT^2 tiles (Gauss-Jordan: all tiles = 2 n^3 flop) or over the NT(NT+1)/2 lower tiles (SPD sweep, one
-    wavefront per matrix: n <= 96; the several-wavefront SPD kernels sweep all tiles), 2048 flop per v_mfma_f64_16x16x4_f64.
+    rank-4 steps over NT^2 tiles (Gauss-Jordan: all tiles = 2 n^3 flop) or over the NT(NT+1)/2 lower tiles (SPD sweep on one or
+    two wavefronts per matrix: n <= 176 in fp64; beyond, one wavefront per tile column sweeps all tiles), 2048 flop per MFMA.
     Blocked two-level Gauss-Jordan (n >= 384): 2 n^3. Blocked SPD inverse (n > 192; update and Y Y^T product on the matrix
     cores): n^3 -- factor, triangular inverse and product at n^3 / 3 each (the 64 x 64 tile granularity issues more)."""
     if n > 192 and algo_name == "gj":
@@ -308,7 +285,7 @@ def mfma_flops_per_inversion(algo_name, n):
     if n <= 16 or n > 192:
         return None
     nt = (n + 15) // 16
-    tiles = nt * nt if (algo_name == "gj" or n > 96) else nt * (nt + 1) // 2
+    tiles = nt * nt if (algo_name == "gj" or n > 176) else nt * (nt + 1) // 2
     # block steps actually executed: the all-padding 4-column blocks of the last tile column are skipped (fp64: ceil(rem / 4))
     steps = 4 * (nt - 1) + (n - 16 * (nt - 1) + 3) // 4
     return steps * tiles * 2048
@@ -539,6 +516,9 @@ def main():
             k2 = api.KERNEL_TILEP if (gen2 and 16 < n2 <= 192 and not natural_first) else api.KERNEL_AUTO
             for _ in range(3):
                 api.inverse_batched(a2, n2, algo2, out=x2, info=i2, batch=b2, kernel=k2)
+            # a caller that has seen one batch of this size class complete: the launcher's reject-rate hint is in, and under the default
+            # policy a general batch then takes the screening pass (csrc/tile_screen.hpp) -- results do not depend on it, the cost does
+            torch.cuda.synchronize()
             ms2 = float(np.mean(time_launches(lambda: api.inverse_batched(a2, n2, algo2, out=x2, batch=b2, kernel=k2), reps)))
             r1, r2 = rooflines(algo2_name, n2, b2, ms2, 4 if f32 else 8)
             kname2 = api.kernel_name(algo2, api.F32 if f32 else api.F64, n2, k2)
@@ -554,8 +534,8 @@ def main():
             del a2, x2
             return d
 
-        for wname in ("gj16", "chol64", "gj32", "gj24", "gj50", "gj8", "gj128", "gj64g", "gj32g", "gj96g", "gj128g", "gj192g", "chol192", "gj256g", "chol256",
-                      "gj1024g", "chol1024", "gj64_f32", "chol64_f32", "gj128_f32", "gj64g_f32"):
+        for wname in ("gj16", "chol64", "gj32", "gj24", "gj50", "gj8", "gj128", "gj64g", "gj32g", "gj96g", "gj128g", "gj192g", "chol128", "chol130",
+                      "chol144", "chol192", "gj256g", "chol256", "gj1024g", "chol1024", "gj64_f32", "chol64_f32", "gj128_f32", "gj64g_f32"):
             if wname == args.workload:
                 continue
             n2 = WORKLOADS[wname][0]
@@ -566,6 +546,33 @@ def main():
             others[wname + f"@{b2 // 1_000_000}M"] = one(wname, b2)
         # what a GENERAL batch costs under the default (per-matrix deterministic) policy: natural-order attempt + pivoting kernel
         others["gj64g@natural_first"] = one("gj64g", 100_000, natural_first=True)
+        others["gj128g@natural_first"] = one("gj128g", 25_000, natural_first=True)
+
+        # the fused mean pipeline (add -> inv -> gemv -> dot, gauss_bench.cu:127-265 of the reference) at two fp64 sizes around the old
+        # 128 -> 130 cliff: kernel-only, device-resident items, checked against torch on a few items
+        def one_mean(n2, b2, reps=5):
+            g = torch.Generator(device=device).manual_seed(0x5EED + 31 * n2)
+            r = torch.rand((b2, n2, n2), generator=g, dtype=torch.float64, device=device)
+            B2 = r + r.transpose(1, 2)
+            B2.diagonal(dim1=1, dim2=2).add_(float(n2))
+            v = torch.rand((3, b2, n2), generator=g, dtype=torch.float64, device=device)
+            a2, c2, d2 = v[0].reshape(-1).contiguous(), v[1].reshape(-1).contiguous(), v[2].reshape(-1).contiguous()
+            Bf = B2.reshape(-1).contiguous()
+            for _ in range(3):
+                m = api.calcluateMean(n2, a2, Bf, c2, d2)
+            torch.cuda.synchronize()
+            ms2 = float(np.mean(time_launches(lambda: api.calcluateMean(n2, a2, Bf, c2, d2), reps)))
+            k = min(8, b2)
+            M = B2[:k] + torch.diag_embed(v[1, :k])
+            want = torch.einsum("bi,bi->b", v[0, :k], torch.linalg.solve(M, v[2, :k].unsqueeze(-1)).squeeze(-1))
+            err = float((m[:k] - want).abs().max())
+            assert err < 1e-11, f"mean{n2}: {err}"
+            alg = b2 * (n2 * n2 + 3 * n2 + 1) * 8
+            return {"kernel": "fused mean pipeline", "dtype": "f64", "batch": b2, "kernel_ms": ms2, "items_per_s": b2 / (ms2 * 1e-3), "bound": "hbm",
+                    "achieved": alg / (ms2 * 1e-3) / 1e9, "unit": "GB/s", "frac": alg / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "max_abs_err_8_items": err}
+
+        others["mean128"] = one_mean(128, 25_000)
+        others["mean130"] = one_mean(130, 25_000)
 
         # End to end, as the reference times it (src/inverse_bench.c:187-200: TIMER around the host-pointer call; H2D + kernel + D2H
         # inside, caller's pageable memory in and out). Never `value`.

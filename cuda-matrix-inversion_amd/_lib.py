@@ -33,7 +33,7 @@ NATIVE_NAMES = [
     "matinv_inverse_batched", "matinv_inverse_batched_ex", "matinv_select_kernel", "matinv_kernel_name",
     "matinv_mean_batched", "matinv_variance_batched", "matinv_inverse_batched_host", "matinv_mean_batched_host",
     "matinv_variance_batched_host", "matinv_last_error",
-    "matinv_abi_version", "matinv_release_cache", "matinv_batched_malloc", "matinv_batched_free", "matinv_memcpy_2d",
+    "matinv_abi_version", "matinv_release_cache", "matinv_stream_retire", "matinv_batched_malloc", "matinv_batched_free", "matinv_memcpy_2d",
     "matinv_device_synchronize", "matinv_tile_stats", "matinv_queue_create", "matinv_queue_submit", "matinv_queue_submit_chunks", "matinv_queue_pending",
     "matinv_queue_bins", "matinv_queue_flush", "matinv_queue_destroy", "matinv_queue_last_error",
     "matinv_set_gj_policy", "matinv_device_count", "matinv_shard_range", "matinv_inverse_batched_host_multi", "matinv_comm_unique_id",

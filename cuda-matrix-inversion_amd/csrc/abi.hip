@@ -289,15 +289,25 @@ int env_devices()
     return v;
 }
 
-// `registered`: the caller (the multi-device driver) has page-locked both host buffers for every device already
+// host_mode (set by the multi-device driver for its per-shard calls): HOST_REGISTERED = both host buffers are page-locked for every
+// device already; HOST_STAGED_ONLY = its up-front page-locking failed -- go straight to the staged copies (a per-shard
+// hipHostRegister would collide with the neighbours' on shared pages: ADVICE r03)
+enum { HOST_DEFAULT = 0, HOST_REGISTERED = 1, HOST_STAGED_ONLY = 2 };
 template <class T>
 int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int *info, const char *log_prefix,
-                 int kernel = MATINV_KERNEL_AUTO, bool single_device = false, bool registered = false)
+                 int kernel = MATINV_KERNEL_AUTO, bool single_device = false, int host_mode = HOST_DEFAULT)
 {
+    const bool registered = host_mode == HOST_REGISTERED;
     if (n < 1) return fail(MATINV_ERR_ARG, "n must be >= 1 (got %d)", n);
     if (batch == 0) return MATINV_OK;
     if (!hA || !hAinv) return fail(MATINV_ERR_ARG, "null host pointer");
-    if (!single_device && env_devices() > 1) return inverse_host_multi<T>(algo, n, hA, hAinv, batch, info, env_devices(), kernel);
+    if (!single_device && env_devices() > 1) {
+        const double t0 = now_ms();
+        const int mrc = inverse_host_multi<T>(algo, n, hA, hAinv, batch, info, env_devices(), kernel);
+        // MATINV_DEVICES > 1 under MATINV_DETAILED_LOGGING: one line for the whole sharded call (the shards overlap: no phase split)
+        if (mrc == MATINV_OK && detailed_logging() && log_prefix) timer_log(log_prefix, "multi_total", batch, n, now_ms() - t0);
+        return mrc;
+    }
     int rc = check_device();
     if (rc) return rc;
     const size_t elems = (size_t)n * n * batch;  // size_t: 1M x 64 x 64 overflows the reference's int index
@@ -308,7 +318,7 @@ int inverse_host(int algo, int n, const void *hA, void *hAinv, size_t batch, int
             return s && *s ? atoi(s) : -1;
         }();
         const bool big = elems * sizeof(T) >= ((size_t)128 << 20);
-        if (hA != hAinv && (registered || mode == 1 || (mode < 0 && big))) {
+        if (hA != hAinv && host_mode != HOST_STAGED_ONLY && (registered || mode == 1 || (mode < 0 && big))) {
             double ms = 0;
             const int prc = inverse_host_pipelined<T>(algo, n, static_cast<const T *>(hA), static_cast<T *>(hAinv), batch, info,
                                                       kernel, ms, registered);
@@ -426,7 +436,8 @@ int inverse_host_multi(int algo, int n, const void *hA, void *hAinv, size_t batc
         workers.emplace_back([=, &res]() {
             hipError_t e = hipSetDevice(dev);
             int r = e == hipSuccess ? inverse_host<T>(algo, n, static_cast<const T *>(hA) + lo * mat, static_cast<T *>(hAinv) + lo * mat,
-                                                      hi - lo, info ? info + lo : nullptr, nullptr, kernel, true, pinned)
+                                                      hi - lo, info ? info + lo : nullptr, nullptr, kernel, true,
+                                                      pinned ? HOST_REGISTERED : (pin ? HOST_STAGED_ONLY : HOST_DEFAULT))
                                     : fail_hip(e, "hipSetDevice");
             res[(size_t)g].rc = r;
             if (r != MATINV_OK) res[(size_t)g].msg = g_err;  // the worker's thread-local message
@@ -521,56 +532,33 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
         if (er != hipSuccess) return fail_hip(er, "kernel launch");
         return MATINV_OK;
     }
-    {
-        static const bool use_tile = []() {
-            const char *s = getenv("MATINV_GP_TILE");  // A/B switch for profiling; default on
-            return !(s && *s == '0');
-        }();
-        static const bool use_spd = []() {
-            const char *s = getenv("MATINV_GP_SPD_TILE");  // A/B switch for profiling; default on
-            return !(s && *s == '0');
-        }();
-        if constexpr (sizeof(T) == 8) {
-            if (use_tile && spd_tile2_supports(true, n)) {  // fp64 112 < n <= 128: two wavefronts, lower tiles only (r03)
-                hipError_t e = launch_gp_spd_tile2(n, static_cast<const double *>(a), static_cast<const double *>(B), static_cast<const double *>(c),
-                                                   variance ? nullptr : static_cast<const double *>(d), static_cast<const double *>(e_),
-                                                   static_cast<double *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
-                if (e != hipSuccess) return fail_hip(e, "kernel launch");
-                return MATINV_OK;
-            }
-        }
-        if (use_tile && use_spd && gp_spd_tile_supports(sizeof(T) == 8, n)) {
-            hipError_t e = launch_gp_spd_tile<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
-                                                 variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
-                                                 static_cast<T *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
-            if (e != hipSuccess) return fail_hip(e, "kernel launch");
-            return MATINV_OK;
-        }
-        if (use_tile && gp_tile_supports(sizeof(T) == 8, n)) {
-            hipError_t e = launch_gp_tile<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
-                                             static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
-                                             static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,
-                                             static_cast<hipStream_t>(stream));
+    // MFMA tile kernels, one or two wavefronts per item, lower tiles only: fp64 112 < n <= 176 on two wavefronts (spd_tile2_impl.hpp),
+    // the SPD sweep with the bilinear form folded out of the accumulators where the bordered form no longer fits one wavefront
+    // (fp64 80 < n <= 112, fp32 96 < n <= 160), the bordered sweep below that. (r01 - r03 kept A/B switches to the older kernels these
+    // replaced -- MATINV_GP_TILE / _GP_SPD_TILE / _GP_TILE4 and a several-wavefront all-tiles pipeline kernel: gone with it in r04.)
+    if constexpr (sizeof(T) == 8) {
+        if (spd_tile2_supports(true, n)) {
+            hipError_t e = launch_gp_spd_tile2(n, static_cast<const double *>(a), static_cast<const double *>(B), static_cast<const double *>(c),
+                                               variance ? nullptr : static_cast<const double *>(d), static_cast<const double *>(e_),
+                                               static_cast<double *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
             if (e != hipSuccess) return fail_hip(e, "kernel launch");
             return MATINV_OK;
         }
     }
-    // One wavefront per tile column up to n = 160: beyond it the blocked path (matrix-core tile products since late r02, five waves
-    // per SIMD since r03) is the faster one -- fp64 176^2: 1.73e6 items/s here, 1.93e6 blocked; fp32 161^2 / 176^2: 3.34e6 / 3.12e6 here,
-    // 3.85e6 / 3.59e6 blocked; at 160^2 fp64 this kernel still leads (2.20e6 / 2.06e6). (The kernel itself serves n <= 192 / 208:
-    // tile4_impl.hpp, gp_tile4_wide_supports.)
-    if (tile4_supports(n) || (n > 128 && n <= 160)) {
-        static const bool use_tile4 = []() {
-            const char *s = getenv("MATINV_GP_TILE4");  // A/B switch for profiling; default on
-            return !(s && *s == '0');
-        }();
-        if (use_tile4) {
-            hipError_t e4 = launch_gp_tile4<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
-                                               variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
-                                               static_cast<T *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
-            if (e4 != hipSuccess) return fail_hip(e4, "kernel launch");
-            return MATINV_OK;
-        }
+    if (gp_spd_tile_supports(sizeof(T) == 8, n)) {
+        hipError_t e = launch_gp_spd_tile<T>(n, static_cast<const T *>(a), static_cast<const T *>(B), static_cast<const T *>(c),
+                                             variance ? nullptr : static_cast<const T *>(d), static_cast<const T *>(e_),
+                                             static_cast<T *>(out), batch, dInfo, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail_hip(e, "kernel launch");
+        return MATINV_OK;
+    }
+    if (gp_tile_supports(sizeof(T) == 8, n)) {
+        hipError_t e = launch_gp_tile<T>(n, static_cast<const T *>(a), static_cast<const T *>(B),
+                                         static_cast<const T *>(c), variance ? nullptr : static_cast<const T *>(d),
+                                         static_cast<const T *>(e_), static_cast<T *>(out), batch, dInfo,
+                                         static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail_hip(e, "kernel launch");
+        return MATINV_OK;
     }
     // measured: the LDS kernel wins while two workgroups fit a CU (f32 up to n = 137: 4.7e6 vs 3.6e6 items/s at 130) and, in
     // f64, over its whole range (2.0e6 vs 1.75e6 at 130); with one f32 workgroup per CU the blocked path wins (3.1e6 vs 1.6e6
@@ -717,6 +705,14 @@ int matinv_release_cache(void)
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail_hip(e, "release cache");
     scratch_release_device();
+    return MATINV_OK;
+}
+int matinv_stream_retire(void *stream)
+{
+    if (!stream) return fail(MATINV_ERR_ARG, "matinv_stream_retire: the null stream is never retired");
+    hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "stream retire");
+    scratch_retire_stream(static_cast<hipStream_t>(stream));
     return MATINV_OK;
 }
 long long matinv_debug_rejects(int reset) { return debug_rejects(reset != 0); }

@@ -124,7 +124,6 @@ hipError_t launch_chol_blocked(int n, BatchRef<const T> A, BatchRef<T> X, size_t
 // rounds of resident workgroups in the grids of the MFMA-tile kernels (each workgroup strides over the batch);
 // MATINV_TILE_GRID_MULT overrides the default for A/B measurements (tile_kernels.hip)
 unsigned tile_grid_rounds();
-bool onewave_wide();  // r03: one-wavefront kernels on VGPRs + AGPRs beyond 256 registers (MATINV_ONEWAVE_WIDE=0: off)
 
 // blocked Gauss-Jordan with partial pivoting for large general matrices (blocked_gj_kernels.hip)
 bool blocked_gj_supports(int n);
@@ -169,10 +168,6 @@ hipError_t launch_gj_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t bat
 template <class T>
 hipError_t launch_spd_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
 const char *name_tile4(bool f64, bool spd, int n);
-// fused GP scalars on the same kernel (SPD sweep of B + diag c, bilinear form from the accumulators), 64 < n <= 128
-template <class T>
-hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
-                           int *info, hipStream_t stream);
 // SPD (symmetric blocked sweep) on the tile layout, f64, n <= 64
 template <class T>
 hipError_t launch_spd_tile(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream);
@@ -211,15 +206,15 @@ template <>
 hipError_t launch_gj_tilep4<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, int *info, hipStream_t stream);
 template <class T>
 hipError_t launch_gj_tilep4_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count, const int *in_list,
-                                     int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out);
+                                     int *bad_count, int *bad_list, int *info, hipStream_t stream, hint_t *hint_out, bool expect_many = false);
 template <>
 hipError_t launch_gj_tilep4_worklist<double>(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, const int *in_count,
                                              const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                             hint_t *hint_out);
+                                             hint_t *hint_out, bool expect_many);
 template <>
 hipError_t launch_gj_tilep4_worklist<float>(int n, BatchRef<const float> A, BatchRef<float> X, size_t batch, const int *in_count,
                                             const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                            hint_t *hint_out);
+                                            hint_t *hint_out, bool expect_many);
 const char *name_gj_tilep4(bool f64, int n);
 // r04: fixed pivot rows, searched pivot columns -- no run-time register index (tileq_kernels.hip): one wavefront per tile column,
 // general 128 < n <= 192 (f64) / 256 (f32). in_count / in_list: work-list form (nullptr: the whole batch); bad_count / bad_list: unused
@@ -275,7 +270,6 @@ hipError_t enqueue_gp_spd_tile_wide_f64(int n, const double *As, const double *B
 hipError_t enqueue_gp_spd_tile_wide_f32(int n, const float *As, const float *Bs, const float *Cs, const float *Ds, const float *Es, float *out,
                                         unsigned grid, unsigned b, int *info, int *ws, hipStream_t stream);
 // two wavefronts per matrix, lower tiles only, fp64 112 < n <= 176 (r04: beyond 128 too): Cholesky entry point and fused pipeline (spd_tile2_kernels.hip);
-// MATINV_SPD_TILE2=0: off
 bool spd_tile2_supports(bool f64, int n);
 hipError_t launch_spd_tile2(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
 hipError_t launch_gp_spd_tile2(int n, const double *As, const double *Bs, const double *Cs, const double *Ds, const double *Es, double *out,

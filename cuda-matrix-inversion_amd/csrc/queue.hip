@@ -119,6 +119,16 @@ int matinv_queue_create(matinv_queue **out, int dtype, const int *bins, int nbin
         e = hipStreamCreateWithFlags(&q->streams[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
     }
+    // r04: bind the two chain streams of this queue to hardware queues NOW, one after the other. HIP binds a stream to one of its
+    // (four) hardware queues at the stream's first command, round-robin over the process; two launch chains that share a hardware
+    // queue do not overlap. Left to the first flush, the binding depended on how many other streams the process had used in between:
+    // the same code ran 0.72 or 0.95 ms per step (bench.py tried four stream sets and kept the best -- VERDICT r03 #6). With the
+    // first command issued here, the chain of the largest pending bin (streams[0]) and the chain of the other bins (streams[1]) sit
+    // on consecutive hardware queues, and so do those of a second queue created right after this one.
+    for (int i = 0; i < nbins && i < 2 && e == hipSuccess; ++i) {
+        e = hipEventRecord(q->done[i], q->streams[i]);
+        if (e == hipSuccess) e = hipStreamSynchronize(q->streams[i]);
+    }
     if (e != hipSuccess) {
         matinv_queue_destroy(q);
         return MATINV_ERR_HIP;

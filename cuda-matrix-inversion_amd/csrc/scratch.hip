@@ -72,13 +72,26 @@ void drop_free_blocks_locked(int dev)
 }
 }  // namespace
 
+// the device a stream belongs to (the null stream: the calling thread's current device). r03 keyed the cache by the CURRENT device:
+// a queue destroyed while another device was current retired nothing, and a block could be filed under the wrong device.
+static hipError_t device_of(hipStream_t stream, int *dev)
+{
+    if (stream) {
+        hipError_t e = hipStreamGetDevice(stream, dev);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+    }
+    return hipGetDevice(dev);
+}
+
 hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t stream)
 {
     *p = nullptr;
     if (bytes == 0) bytes = 1;
     bytes = (bytes + 255) & ~(size_t)255;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    int dev = 0, cur = 0;
+    hipError_t e = device_of(stream, &dev);
+    if (e == hipSuccess) e = hipGetDevice(&cur);
     if (e != hipSuccess) return e;
     const Key key{dev, stream};
     std::lock_guard<std::mutex> lock(g_mu);
@@ -102,7 +115,8 @@ hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t stream)
         return hipSuccess;
     }
     void *q = nullptr;
-    e = hipMalloc(&q, bytes);
+    if (cur != dev) e = hipSetDevice(dev);  // the block lives on the stream's device, whatever device the caller is on
+    if (e == hipSuccess) e = hipMalloc(&q, bytes);
     if (e == hipErrorOutOfMemory) {
         // hand the cache back to the driver and try once more
         (void)hipGetLastError();
@@ -111,6 +125,7 @@ hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t stream)
             e = hipMalloc(&q, bytes);
         }
     }
+    if (cur != dev) (void)hipSetDevice(cur);
     if (e != hipSuccess) return e;
     g_owned[key].push_back(Block{q, bytes, true});
     g_where[q] = key;
@@ -137,7 +152,7 @@ hipError_t scratch_free(void *p, hipStream_t /*stream*/)
 void scratch_retire_stream(hipStream_t stream)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
+    if (device_of(stream, &dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_owned.find(Key{dev, stream});
     if (it == g_owned.end()) return;

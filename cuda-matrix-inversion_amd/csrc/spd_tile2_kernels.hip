@@ -8,13 +8,7 @@
 
 namespace matinv {
 
-// MATINV_SPD_TILE2=0: these sizes stay on the kernels that sweep all tiles (four wavefronts per matrix up to n = 128, one per tile
-// column beyond) -- A/B switch
-bool spd_tile2_supports(bool f64, int n)
-{
-    static const bool on = [] { const char *s = getenv("MATINV_SPD_TILE2"); return !(s && *s == '0'); }();
-    return on && f64 && n > 112 && n <= 176;
-}
+bool spd_tile2_supports(bool f64, int n) { return f64 && n > 112 && n <= 176; }
 
 template <bool GP>
 static hipError_t launch_tile2(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream, int *ws,

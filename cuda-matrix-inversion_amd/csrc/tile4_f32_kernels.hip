@@ -5,7 +5,5 @@ namespace matinv {
 
 template hipError_t launch_gj_tile4<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
 template hipError_t launch_spd_tile4<float>(int, BatchRef<const float>, BatchRef<float>, size_t, int *, hipStream_t);
-template hipError_t launch_gp_tile4<float>(int, const float *, const float *, const float *, const float *, const float *, float *,
-                                           size_t, int *, hipStream_t);
 
 }  // namespace matinv

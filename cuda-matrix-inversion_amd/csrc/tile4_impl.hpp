@@ -21,6 +21,7 @@
 #include <cstdio>
 
 #include "tile_common.hpp"
+#include "tile_screen.hpp"
 
 namespace matinv {
 
@@ -32,20 +33,14 @@ namespace matinv {
 // tiles are mirrored while loading, as the Cholesky contract demands -- include/matinv.h), the natural pivots are accepted
 // when they are all POSITIVE (leading principal minors of a symmetric matrix: positive definite; no multiplier test, the
 // sweep is stable on SPD input), and rejected matrices go to the LDS Cholesky, which reports the failing column.
-// GP = the fused Gaussian-process scalars for 64 < n <= 128 (SPD mode on M = B + diag c): the diagonal is added while
-// loading, and instead of storing M^-1 every wave folds its tile columns into a^T M^-1 d straight from the accumulator
-// registers (wave reduction, four partial sums through LDS): n^2 elements read, ONE scalar written per item.
-template <class T>
-struct GpArgs {
-    const T *a, *c, *d, *e;  // d == nullptr: variance, out = e - a^T M^-1 a
-    T *out;
-};
-
-template <class T, int NT, bool FULL, int T4_WAVES, bool SPD, bool GP = false>
+// (r01 - r03 also ran the fused mean / variance on this kernel -- a GP mode that added diag c while loading and folded a^T M^-1 d out
+// of the accumulators. Since r04 every size it served has a lower-tile kernel: gp_tile / gp_spd_tile up to n = 112 / 128,
+// spd_tile2_impl.hpp up to 176 in fp64, gp_spd_wide_f32 up to 160 in fp32, the blocked path beyond; the mode and its switch are gone.)
+template <class T, int NT, bool FULL, int T4_WAVES, bool SPD>
 __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T> Xout, int *info, int n_rt, unsigned batch,
-                                              int *work_count, int *work_list, T *panel, GpArgs<T> gp = GpArgs<T>())
+                                              int *work_count, int *work_list, T *panel, const int *in_count = nullptr,
+                                              const int *in_list = nullptr)
 {
-    static_assert(!GP || SPD, "the fused pipeline runs the SPD sweep");
     // NT > 8, SPD sweep: no Cholesky kernel behind this one serves every such n, so a matrix that is not positive definite is
     // finished here: info = the column of the first non-positive pivot + 1 (the Cholesky contract), output NaN-filled.
     // (Gauss-Jordan, NT > 8: rejected = needs row exchanges -> work list -> the pivoting kernel of that size, tileq_impl.hpp)
@@ -58,7 +53,10 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
     const int l = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;  // wave-uniform
 
-    for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
+    // accept-list form (behind the screening kernel, tile_screen.hpp): in_list[0 .. *in_count)
+    const unsigned todo = in_count ? (unsigned)*in_count : batch;
+    for (unsigned item = blockIdx.x; item < todo; item += gridDim.x) {
+        const unsigned mat = in_list ? (unsigned)in_list[item] : item;
         const T *A = Ain.at_uniform(mat);
         T *X = Xout.at_uniform(mat);
         // run-time n made opaque once per matrix: keeps LICM from hoisting the tile offsets and bounds predicates of the
@@ -87,10 +85,6 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                     // A(col, row); its mirror A(row, col) sits at col * n + row
                     const bool mirror = SPD && (col < row);  // A(col,row) with col < row is an UPPER element: read A(row,col)
                     acc[ti][jl][r] = in ? (mirror ? A[(unsigned)(col * n + row)] : A[uoff + lane_off]) : ((row == col) ? (T)1 : (T)0);
-                    // addDiagonal (gauss_bench.cu:38-43): only the tile slot that can hold the diagonal tile of this tile row
-                    if (GP && jl == ti / T4_WAVES) {
-                        if (w == ti % T4_WAVES && row == col && (FULL || row < n)) acc[ti][jl][r] += gp.c[(size_t)mat * n + row];
-                    }
                 }
             }
         unsigned long long bad = 0;
@@ -225,47 +219,7 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
         }
         __syncthreads();  // both panel buffers are free again before the next matrix stages its first panel
 
-        if (GP) {
-            if (bad == 0) {
-                // s = sum over this lane's elements a[row] X[row][col] d[col] (X symmetric, so the W = A^T labelling is immaterial)
-                const T *va = gp.a + (size_t)mat * n;
-                const T *vd = gp.d ? gp.d + (size_t)mat * n : va;
-                T s = 0;
-#pragma unroll
-                for (int jl = 0; jl < NC; ++jl) {
-                    const int tj = w + T4_WAVES * jl, col = 16 * tj + c;
-                    T t = 0;
-#pragma unroll
-                    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * ti + G::trow(r, q);
-                            const T ar = (FULL || ti < NT - 1 || row < n) ? va[row] : (T)0;  // identity padding contributes nothing
-                            t = fma_t(ar, acc[ti][jl][r], t);
-                        }
-                    const T dc = (tj < NT && (FULL || col < n)) ? vd[col] : (T)0;
-                    s = fma_t(dc, t, s);
-                }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-                if (l == 0) panel[w] = s;  // both panel buffers are free (barrier above)
-            }
-            __syncthreads();
-            if (bad == 0 && threadIdx.x == 0) {
-                T sum = 0;
-#pragma unroll
-                for (int i = 0; i < T4_WAVES; ++i) sum += panel[i];
-                gp.out[mat] = gp.d ? sum : gp.e[mat] - sum;
-            }
-            if (SELF && bad != 0 && threadIdx.x == 0) {
-                gp.out[mat] = nan_of<T>();
-                if (info) info[mat] = badinfo;
-            }
-            __syncthreads();  // the next matrix stages its first panel into the same buffer
-        }
-        if (GP && bad == 0) {
-            if (info && threadIdx.x == 0) info[mat] = 0;
-        } else if (bad == 0) {  // identical in all four waves (they evaluate the same D and the same Aop)
+        if (bad == 0) {  // identical in all four waves (they evaluate the same D and the same Aop)
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -281,12 +235,10 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
                 }
             if (info && threadIdx.x == 0) info[mat] = 0;
         } else if (SELF) {
-            if (!GP) {
-                // (a plain strided fill: written over the tile structure, the 16 NT address offsets of this rare path are
-                // hoisted out of the batch loop by LICM and the whole kernel spills -- 4 700 VGPR spills at 12 x 12 tiles)
-                for (unsigned e = threadIdx.x; e < (unsigned)(n * n); e += 64u * T4_WAVES) X[e] = nan_of<T>();
-                if (info && threadIdx.x == 0) info[mat] = badinfo;
-            }
+            // (a plain strided fill: written over the tile structure, the 16 NT address offsets of this rare path are
+            // hoisted out of the batch loop by LICM and the whole kernel spills -- 4 700 VGPR spills at 12 x 12 tiles)
+            for (unsigned e = threadIdx.x; e < (unsigned)(n * n); e += 64u * T4_WAVES) X[e] = nan_of<T>();
+            if (info && threadIdx.x == 0) info[mat] = badinfo;
         } else if (threadIdx.x == 0) {
             const int slot = atomicAdd(work_count, 1);
             work_list[slot] = (int)mat;
@@ -298,42 +250,20 @@ __device__ __forceinline__ void gj_tile4_body(BatchRef<const T> Ain, BatchRef<T>
 template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
 __global__ __launch_bounds__(64 * T4_WAVES, T4_WAVES > 4 ? 1 : ((NT <= 4) ? 3 : 2)) void matinv_gj_tile4_f64(BatchRef<const double> Ain, BatchRef<double> Xout,
                                                                        int *info, int n_rt, unsigned batch,
-                                                                       int *work_count, int *work_list)
+                                                                       int *work_count, int *work_list, const int *in_count,
+                                                                       const int *in_list)
 {
     __shared__ __attribute__((aligned(16))) double panel[2 * 16 * NT * 4];  // double buffered [row][4 pivot columns]
-    gj_tile4_body<double, NT, FULL, T4_WAVES, SPD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
+    gj_tile4_body<double, NT, FULL, T4_WAVES, SPD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel, in_count, in_list);
 }
 // fp32 (the reference's DataType; its benchmark sweep goes up to n = 128): 16 tiles x 4 VGPRs per wave
 template <int NT, bool FULL, int T4_WAVES = 4, bool SPD = false>
 __global__ __launch_bounds__(64 * T4_WAVES, T4_WAVES > 4 ? 1 : (T4_WAVES <= 2 ? 2 : 3)) void matinv_gj_tile4_f32(BatchRef<const float> Ain, BatchRef<float> Xout, int *info,
-                                                                       int n_rt, unsigned batch, int *work_count, int *work_list)
+                                                                       int n_rt, unsigned batch, int *work_count, int *work_list,
+                                                                       const int *in_count, const int *in_list)
 {
     __shared__ __attribute__((aligned(16))) float panel[2 * 16 * NT * 4];
-    gj_tile4_body<float, NT, FULL, T4_WAVES, SPD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel);
-}
-
-// fused mean / variance, 64 < n <= 128 (run-time n only: one instantiation per NT and dtype)
-template <int NT, int W>
-__global__ __launch_bounds__(64 * W, W > 4 ? 1 : 2) void matinv_gp_tile4_f64(const double *As, const double *Bs, const double *Cs, const double *Ds,
-                                                             const double *Es, double *out, int *info, int n_rt, unsigned batch,
-                                                             int *work_count, int *work_list)
-{
-    __shared__ __attribute__((aligned(16))) double panel[2 * 16 * NT * 4];
-    BatchRef<const double> A{Bs, (size_t)n_rt * n_rt, nullptr};
-    BatchRef<double> X{nullptr, 0, nullptr};
-    gj_tile4_body<double, NT, false, W, true, true>(A, X, info, n_rt, batch, work_count, work_list, panel,
-                                                   GpArgs<double>{As, Cs, Ds, Es, out});
-}
-template <int NT, int W>
-__global__ __launch_bounds__(64 * W, W > 4 ? 1 : (W <= 2 ? 2 : 3)) void matinv_gp_tile4_f32(const float *As, const float *Bs, const float *Cs, const float *Ds,
-                                                             const float *Es, float *out, int *info, int n_rt, unsigned batch,
-                                                             int *work_count, int *work_list)
-{
-    __shared__ __attribute__((aligned(16))) float panel[2 * 16 * NT * 4];
-    BatchRef<const float> A{Bs, (size_t)n_rt * n_rt, nullptr};
-    BatchRef<float> X{nullptr, 0, nullptr};
-    gj_tile4_body<float, NT, false, W, true, true>(A, X, info, n_rt, batch, work_count, work_list, panel,
-                                                  GpArgs<float>{As, Cs, Ds, Es, out});
+    gj_tile4_body<float, NT, FULL, T4_WAVES, SPD>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel, in_count, in_list);
 }
 
 // Wavefronts per matrix, by measurement (inv/s, FULL Gauss-Jordan, 1 / 2 / 3 / 4 waves; "-" = does not fit or spills badly):
@@ -350,52 +280,85 @@ __global__ __launch_bounds__(64 * W, W > 4 ? 1 : (W <= 2 ? 2 : 3)) void matinv_g
 // against 3.0e6 / 2.66e6 -- 200+ B of scratch there, and every wave's redundant panel solve now serves two columns' worth of waiting)
 constexpr int t4_waves(bool f64, int nt) { return nt > 8 ? nt : (f64 ? (nt <= 6 ? 2 : 4) : (nt <= 5 ? 1 : (nt <= 7 ? 2 : 4))); }
 constexpr int t4_wide_limit(bool f64) { return f64 ? 192 : 256; }
-// the fused pipeline in f32 stops at 13 x 13 tiles: at 256 the blocked path is faster (1.4e6 items/s against 1.0e6)
-constexpr bool gp_tile4_wide_supports(bool f64, int n) { return n > 128 && n <= (f64 ? 192 : 208); }
 
 template <class T, bool SPD>
 static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
     if (!(tile4_supports(n) || (n > 128 && n <= t4_wide_limit(sizeof(T) == 8)))) return hipErrorInvalidValue;
+    // SPD sweep: only the sizes no lower-tile kernel serves (fp64 176 < n <= 192, fp32 160 < n <= 256) are instantiated since r04
+    if (SPD && (n + 15) / 16 < (sizeof(T) == 8 ? 12 : 11)) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
     // Gauss-Jordan: general batches go straight to the PIVOTING kernel of this size once a natural-order launch of this size
     // has seen most of its matrices rejected (tile_kernels.inc "natural order or pivot search?")
     if (!SPD && tile_policy_use_pivot(sizeof(T) == 8, (n + 15) / 16))
         return n > 128 ? launch_gj_tileq<T>(n, A, X, batch, info, stream, nullptr, nullptr, nullptr, nullptr, nullptr)
                        : launch_gj_tilep4<T>(n, A, X, batch, info, stream);
-    // [0], [1] = counts; [2 .. batch+2) = rejected matrices; [batch+2 ..) = (Gauss-Jordan) the singular ones among them
+    // [0], [1] = counts; [2 .. batch+2) = rejected matrices; [batch+2 ..) = (Gauss-Jordan) the singular ones among them; behind the
+    // screening pass (r04, tile_screen.hpp: general batches under the default policy) [2 batch + 4] = count of the accepted matrices,
+    // then their list
+    const int nt = (n + 15) / 16;
+    const bool screen = !SPD && tile_policy_use_screen(sizeof(T) == 8, nt);
     int *ws = nullptr;
-    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (2 * batch + 2) * sizeof(int), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), ((screen ? 3 : 2) * batch + 6) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, 2 * sizeof(int), stream);
+    if (e == hipSuccess && screen) e = hipMemsetAsync(ws + 2 * batch + 4, 0, sizeof(int), stream);
     if (e != hipSuccess) {
         (void)scratch_free(ws, stream);
         return e;
     }
-    const int nt = (n + 15) / 16;
+    int *const acc_count = ws + 2 * batch + 4, *const acc_list = ws + 2 * batch + 5;
+    const int *const in_count = screen ? acc_count : nullptr, *const in_list = screen ? acc_list : nullptr;
     const unsigned resident = nt > 8 ? 256u : 256u * 3u;  // NT wavefronts per matrix: one workgroup per CU
+    const unsigned sgrid = (unsigned)(batch < 256u * 16u ? batch : 256u * 16u);  // screening: every resident wave takes many matrices
     const unsigned grid = (unsigned)(batch < resident * tile_grid_rounds() ? batch : resident * tile_grid_rounds());
     const unsigned b = (unsigned)batch;
 // more than 8 x 8 tiles: run-time n only, f64 up to 12 x 12
 #define T4_WIDE(NT_)                                                                                                  \
-    if constexpr (sizeof(T) == 4 || NT_ <= 12) {                                                             \
+    if constexpr ((sizeof(T) == 4 || NT_ <= 12) && (!SPD || NT_ >= (sizeof(T) == 8 ? 12 : 11))) {                                                             \
         if constexpr (sizeof(T) == 8)                                                                                 \
-            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 2); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 2, in_count, in_list); \
         else                                                                                                          \
-            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 2); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, NT_, SPD>), dim3(grid), dim3(64 * NT_), 0, stream, A, X, info, n, b, ws, ws + 2, in_count, in_list); \
     }
 #define T4_LAUNCH(NT_)                                                                                                \
-    if constexpr (sizeof(T) == 8) {                                                                                   \
+    if constexpr (SPD) {                                                                                              \
+        /* not instantiated: the lower-tile kernels serve every SPD n <= 128 (refused at the top of this function) */     \
+    } else if constexpr (sizeof(T) == 8) {                                                                                   \
         if (n == 16 * NT_)                                                                                            \
-            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, true, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2, in_count, in_list); \
         else                                                                                                          \
-            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f64<NT_, false, t4_waves(true, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2, in_count, in_list); \
     } else {                                                                                                          \
         if (n == 16 * NT_)                                                                                            \
-            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, true, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, true, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2, in_count, in_list); \
         else                                                                                                          \
-            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2); \
+            hipLaunchKernelGGL((matinv_gj_tile4_f32<NT_, false, t4_waves(false, NT_), SPD>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, A, X, info, n, b, ws, ws + 2, in_count, in_list); \
     }
+#define T4_SCREEN(NT_)                                                                                                \
+    if constexpr (!SPD && (sizeof(T) == 4 || NT_ <= 12)) {                                                            \
+        if constexpr (sizeof(T) == 8)                                                                                 \
+            hipLaunchKernelGGL((matinv_gj_tile4_screen_f64<NT_>), dim3(sgrid), dim3(64), 0, stream, A, n, b, ws, ws + 2, acc_count, acc_list); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((matinv_gj_tile4_screen_f32<NT_>), dim3(sgrid), dim3(64), 0, stream, A, n, b, ws, ws + 2, acc_count, acc_list); \
+    }
+    if (screen) {
+        switch (nt) {
+        case 5: T4_SCREEN(5) break;
+        case 6: T4_SCREEN(6) break;
+        case 7: T4_SCREEN(7) break;
+        case 8: T4_SCREEN(8) break;
+        case 9: T4_SCREEN(9) break;
+        case 10: T4_SCREEN(10) break;
+        case 11: T4_SCREEN(11) break;
+        case 12: T4_SCREEN(12) break;
+        case 13: T4_SCREEN(13) break;
+        case 14: T4_SCREEN(14) break;
+        case 15: T4_SCREEN(15) break;
+        default: T4_SCREEN(16) break;
+        }
+    }
+#undef T4_SCREEN
     switch (nt) {
     case 5: T4_LAUNCH(5) break;
     case 6: T4_LAUNCH(6) break;
@@ -418,7 +381,7 @@ static hipError_t launch_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t
             if (nt <= 8) e = launch_chol_lds_worklist<T>(n, A, X, ws, ws + 2, info, stream);
         } else if (nt <= 8) {  // rejected = needs row exchanges: the PIVOTING kernel of this size, in the same stream
             e = launch_gj_tilep4_worklist<T>(n, A, X, batch, ws, ws + 2, ws + 1, ws + 2 + batch, info, stream,
-                                             tile_policy_record(sizeof(T) == 8, nt, batch));
+                                             tile_policy_record(sizeof(T) == 8, nt, batch), screen);
         } else {
             e = launch_gj_tileq<T>(n, A, X, batch, info, stream, ws, ws + 2, tile_policy_record(sizeof(T) == 8, nt, batch), nullptr, nullptr);
         }
@@ -436,54 +399,5 @@ template <class T>
 hipError_t launch_spd_tile4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream)
 {
     return launch_tile4<T, true>(n, A, X, batch, info, stream);
-}
-template <class T>
-hipError_t launch_gp_tile4(int n, const T *As, const T *Bs, const T *Cs, const T *Ds, const T *Es, T *out, size_t batch,
-                           int *info, hipStream_t stream)
-{
-    if (!(tile4_supports(n) || gp_tile4_wide_supports(sizeof(T) == 8, n))) return hipErrorInvalidValue;
-    if (batch == 0) return hipSuccess;
-    int *ws = nullptr;
-    hipError_t e = scratch_alloc(reinterpret_cast<void **>(&ws), (batch + 1) * sizeof(int), stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws, 0, sizeof(int), stream);
-    if (e != hipSuccess) {
-        (void)scratch_free(ws, stream);
-        return e;
-    }
-    const int nt = (n + 15) / 16;
-    const unsigned occ = nt > 8 ? 1u : (sizeof(T) == 8 ? 2u : 3u);
-    const unsigned grid = (unsigned)(batch < 256u * occ * tile_grid_rounds() ? batch : 256u * occ * tile_grid_rounds());
-    const unsigned b = (unsigned)batch;
-#define GP4_LAUNCH(NT_)                                                                                               \
-    if constexpr (sizeof(T) == 8)                                                                                     \
-        hipLaunchKernelGGL((matinv_gp_tile4_f64<NT_, t4_waves(true, NT_)>), dim3(grid), dim3(64 * t4_waves(true, NT_)), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1); \
-    else                                                                                                              \
-        hipLaunchKernelGGL((matinv_gp_tile4_f32<NT_, t4_waves(false, NT_)>), dim3(grid), dim3(64 * t4_waves(false, NT_)), 0, stream, As, Bs, Cs, Ds, Es, out, info, n, b, ws, ws + 1);
-    switch (nt) {
-    case 5: GP4_LAUNCH(5) break;
-    case 6: GP4_LAUNCH(6) break;
-    case 7: GP4_LAUNCH(7) break;
-    case 8: GP4_LAUNCH(8) break;
-    case 9: GP4_LAUNCH(9) break;
-    case 10: GP4_LAUNCH(10) break;
-    case 11: GP4_LAUNCH(11) break;
-    case 12: GP4_LAUNCH(12) break;
-    default:
-        if constexpr (sizeof(T) == 4) {
-            switch (nt) {
-            case 13: GP4_LAUNCH(13) break;
-            case 14: GP4_LAUNCH(14) break;
-            case 15: GP4_LAUNCH(15) break;
-            default: GP4_LAUNCH(16) break;
-            }
-        }
-        break;
-    }
-#undef GP4_LAUNCH
-    e = hipGetLastError();
-    if (e == hipSuccess && nt <= 8) e = launch_gp_lds_worklist<T>(n, As, Bs, Cs, Ds, Es, out, ws, ws + 1, info, stream);
-    hipError_t e2 = scratch_free(ws, stream);
-    return e != hipSuccess ? e : e2;
 }
 }  // namespace matinv

@@ -10,8 +10,6 @@ bool tile4_wide_supports(bool f64, int n) { return n > 128 && n <= t4_wide_limit
 
 template hipError_t launch_gj_tile4<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
 template hipError_t launch_spd_tile4<double>(int, BatchRef<const double>, BatchRef<double>, size_t, int *, hipStream_t);
-template hipError_t launch_gp_tile4<double>(int, const double *, const double *, const double *, const double *, const double *,
-                                            double *, size_t, int *, hipStream_t);
 
 const char *name_tile4(bool f64, bool spd, int n)
 {

@@ -395,11 +395,11 @@ __global__ __launch_bounds__(256, 3) void matinv_gj_tilep4_f32(BatchRef<const fl
 
 template <class T>
 static hipError_t enqueue_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, int *info, hipStream_t stream, int *bad_count,
-                                 int *bad_list, const int *in_count, const int *in_list, hint_t *hint_out)
+                                 int *bad_list, const int *in_count, const int *in_list, hint_t *hint_out, bool expect_many = false)
 {
     const int nt = (n + 15) / 16;
     unsigned cap = 256u * 4u * tile_grid_rounds();
-    if (in_list) cap = 256u * 4u;  // usually empty: one round of resident workgroups
+    if (in_list && !expect_many) cap = 256u * 4u;  // usually empty: one round of resident workgroups (see enqueue_tilep)
     const unsigned grid = (unsigned)(batch < cap ? batch : cap);
     const unsigned b = (unsigned)batch;
 #define TP4_LAUNCH(NT_)                                                                                                \
@@ -462,9 +462,9 @@ static hipError_t launch_tilep4(int n, BatchRef<const T> A, BatchRef<T> X, size_
 template <class T>
 static hipError_t launch_tilep4_worklist(int n, BatchRef<const T> A, BatchRef<T> X, size_t batch, const int *in_count,
                                          const int *in_list, int *bad_count, int *bad_list, int *info, hipStream_t stream,
-                                         hint_t *hint_out)
+                                         hint_t *hint_out, bool expect_many = false)
 {
-    hipError_t e = enqueue_tilep4<T>(n, A, X, batch, info, stream, bad_count, bad_list, in_count, in_list, hint_out);
+    hipError_t e = enqueue_tilep4<T>(n, A, X, batch, info, stream, bad_count, bad_list, in_count, in_list, hint_out, expect_many);
     if (e == hipSuccess) e = launch_gj_lds_worklist<T>(n, A, X, bad_count, bad_list, info, stream);
     if (e == hipSuccess) e = debug_note_rejects(in_count, stream);
     return e;

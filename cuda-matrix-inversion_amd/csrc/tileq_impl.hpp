@@ -505,11 +505,10 @@ static hipError_t enqueue_tileq(int n, BatchRef<const T> A, BatchRef<T> X, size_
     if (in_list) cap = 256u * per_cu;  // usually empty: one round of resident workgroups
     const unsigned grid = (unsigned)(batch < cap ? batch : cap);
     const unsigned b = (unsigned)batch;
+// (run-time n only: at these sizes the kernel is far from memory-bound, the compile-time-n twins bought nothing measurable and doubled
+// the build time of this family)
 #define TQ_LAUNCH(KERN, NT_, THREADS)                                                                                  \
-    if (n == 16 * NT_)                                                                                                 \
-        hipLaunchKernelGGL((KERN<NT_, true>), dim3(grid), dim3(THREADS), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out); \
-    else                                                                                                               \
-        hipLaunchKernelGGL((KERN<NT_, false>), dim3(grid), dim3(THREADS), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out);
+    hipLaunchKernelGGL((KERN<NT_, false>), dim3(grid), dim3(THREADS), 0, stream, A, X, info, n, b, bad_count, bad_list, in_count, in_list, hint_out);
 #define TQ_CASEW(NT_)                                                                                                  \
     case NT_:                                                                                                          \
         if constexpr (sizeof(T) == 8) {                                                                                \

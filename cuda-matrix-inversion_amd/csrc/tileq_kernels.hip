@@ -17,7 +17,7 @@ hipError_t launch_gj_tileq<double>(int n, BatchRef<const double> A, BatchRef<dou
 const char *name_gj_tileq(bool f64, int n)
 {
     static thread_local char buf[48];
-    snprintf(buf, sizeof buf, "matinv_gj_tileqw_%s<%d, %s>", f64 ? "f64" : "f32", (n + 15) / 16, (n % 16) == 0 ? "true" : "false");
+    snprintf(buf, sizeof buf, "matinv_gj_tileqw_%s<%d, false>", f64 ? "f64" : "f32", (n + 15) / 16);
     return buf;
 }
 

@@ -217,6 +217,10 @@ int matinv_abi_version(void);
  * device and hands everything that is not in use back to the driver.
  * Returns MATINV_OK, or MATINV_ERR_HIP / MATINV_ERR_NO_DEVICE. Never needed for correctness. */
 int matinv_release_cache(void);
+/* A caller that is about to destroy one of ITS streams on which it has called this library: synchronises the stream and hands the
+ * scratch blocks cached for it (work lists, blocked-path workspaces: they are kept per (device, stream) and reused on that stream
+ * only) to the other streams of its device. Without it they stay cached until matinv_release_cache() or memory runs out. */
+int matinv_stream_retire(void *stream);
 
 /* Test hook. With MATINV_DEBUG_REJECTS=1 in the environment when the library is loaded, every launcher whose first-pass kernel
  * hands rejected matrices (needs row exchanges / not positive definite / singular) to a second kernel through a work list reads

@@ -66,7 +66,7 @@ def test_kernel_selection_is_pure_host_logic():
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F64, 193) == api.KERNEL_BLOCKED
     assert api.select_kernel(api.ALGO_GAUSS_JORDAN, api.F32, 257) == api.KERNEL_BLOCKED
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160) == "matinv_gj_tile4_f64<10, false, 10, false>"
-    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160, api.KERNEL_TILEP) == "matinv_gj_tileqw_f64<10, true>"  # r04: pivot columns searched
+    assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 160, api.KERNEL_TILEP) == "matinv_gj_tileqw_f64<10, false>"  # r04: pivot columns searched
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F64, 128, api.KERNEL_TILEP) == "matinv_gj_tilep4_f64<8, true>"
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 96, api.KERNEL_TILEP) == "matinv_gj_tilep3_f32<6, true>"
     # 16 < n <= 25: the natural-order pass of the tile family is the two-rows-per-lane kernel (csrc/rowlane2_kernels.hip)

@@ -18,8 +18,9 @@ SETTINGS = [
     # Gauss-Jordan policy and the screening pass in front of the natural-order kernel
     ({"MATINV_GJ_POLICY": "pivot"}, ["gj_mixed:f64:64:60", "gj_mixed:f32:48:60", "gj_mixed:f64:100:30", "gj_mixed:f64:160:12"]),
     ({"MATINV_GJ_POLICY": "adaptive"}, ["gj_general:f64:64:60", "gj_mixed:f64:64:60", "gj_general:f32:100:30", "gj_mixed:f64:144:12"]),
-    ({"MATINV_TILE_SCREEN": "1"}, ["gj_mixed:f64:64:90", "gj_mixed:f64:50:90", "gj_mixed:f32:64:90", "gj_mixed:f32:40:90", "gj_spd:f64:32:40"]),
-    ({"MATINV_TILE_SCREEN": "0"}, ["gj_mixed:f64:64:90", "gj_general:f64:50:40", "gj_mixed:f32:64:90"]),
+    ({"MATINV_TILE_SCREEN": "1"}, ["gj_mixed:f64:64:90", "gj_mixed:f64:50:90", "gj_mixed:f32:64:90", "gj_mixed:f32:40:90", "gj_spd:f64:32:40",
+                                   "gj_mixed:f64:100:45", "gj_mixed:f64:128:30", "gj_mixed:f64:160:18", "gj_mixed:f32:96:45", "gj_mixed:f32:200:18"]),
+    ({"MATINV_TILE_SCREEN": "0"}, ["gj_mixed:f64:64:90", "gj_general:f64:50:40", "gj_mixed:f32:64:90", "gj_mixed:f64:112:30", "gj_mixed:f32:144:18"]),
     # several small matrices per wavefront
     ({"MATINV_ROWLANE_BLOCKS_PER_CU": "2"}, ["gj_spd:f64:8:500", "gj_general:f64:16:300", "gj_spd:f32:12:300"]),
     ({"MATINV_ROWLANE2": "0"}, ["gj_spd:f64:20:60", "gj_mixed:f64:24:60", "gj_spd:f32:25:60"]),
@@ -27,13 +28,8 @@ SETTINGS = [
     ({"MATINV_ROWLANE2_GP": "0"}, ["mean:f64:20:60", "variance:f64:24:60", "mean:f32:18:60"]),
     # one wavefront per matrix
     ({"MATINV_TILE_GRID_MULT": "1"}, ["gj_spd:f64:64:5000", "chol:f64:48:5000", "mean:f64:64:5000"]),
-    ({"MATINV_ONEWAVE_WIDE": "0"}, ["chol:f64:100:30", "chol:f64:112:30", "chol:f32:150:20", "mean:f64:100:30", "mean:f32:120:30"]),
-    ({"MATINV_SPD_TILE2": "0"}, ["chol:f64:120:30", "chol:f64:128:30", "mean:f64:128:30", "chol:f64:144:12", "mean:f64:160:12", "variance:f64:176:12"]),
     # fused mean / variance dispatch
     ({"MATINV_GP_ROWLANE": "0"}, ["mean:f64:8:100", "variance:f64:16:100", "mean:f32:12:100"]),
-    ({"MATINV_GP_TILE": "0"}, ["mean:f64:32:60", "variance:f64:64:60", "mean:f32:80:40"]),
-    ({"MATINV_GP_SPD_TILE": "0"}, ["mean:f64:96:30", "variance:f64:112:30", "mean:f32:128:30"]),
-    ({"MATINV_GP_TILE4": "0"}, ["mean:f64:120:30", "variance:f64:100:30", "mean:f32:128:30"]),
     ({"MATINV_GP_BLOCKED": "0"}, ["mean:f64:136:20", "mean:f32:190:20", "variance:f64:130:20"]),
     # blocked multi-launch paths
     ({"MATINV_BGJ_TWO_LEVEL_MIN": "1000"}, ["gj_general:f64:320:12", "gj_general:f32:400:8"]),
@@ -74,6 +70,7 @@ def test_every_switch_of_the_library_is_listed():
     elsewhere = {"MATINV_DEVICES", "MATINV_DEBUG_REJECTS", "MATINV_BLOCKED_WS_MB", "MATINV_DETAILED_LOGGING"}
     here = {k for env, _ in SETTINGS for k in env}
     assert found - here - elsewhere == set(), f"switches without a test: {sorted(found - here - elsewhere)}"
+    assert here - found == set(), f"settings for switches the library no longer has: {sorted(here - found)}"
     for name in elsewhere:
         hits = [f for f in os.listdir(os.path.join(ROOT, "tests")) if f.endswith(".py") and f != os.path.basename(__file__)
                 and name in open(os.path.join(ROOT, "tests", f)).read()]

@@ -3,7 +3,7 @@
 # usage (inside gpurun): bash tools/profile_round.sh r01
 # Kernel trace and PMC counters are taken in SEPARATE passes (gpurun refuses --pmc together with sys/runtime tracing).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 W=/tmp/matinv_prof_$$
@@ -18,15 +18,15 @@ python3 $R/tools/rocprof_summary.py $W/trace_results.db "$TAG: rocprofv3 --kerne
 rocprofv3 --kernel-trace --stats -d $W -o headline -- python3 $R/bench.py --steps 20 --warmup 5 --no-others --no-cpu-baseline > $OUT/${TAG}_bench_headline.json 2> $W/headline.err
 python3 $R/tools/rocprof_summary.py $W/headline_results.db "$TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-others --no-cpu-baseline (the headline workload alone: every launch of its kernel is one 100 000-matrix step)" > $OUT/${TAG}_bench_headline_kernel_trace.txt
 
-for w in gj64 gj16 gj24 gj32 chol64 gj128 gj64g gj32g gj128g; do
+for w in gj64 gj16 gj24 gj32 chol64 gj128 gj64g gj32g gj128g gj192g chol144; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c -d $W -o ${w}_$c -- python3 $R/bench.py --workload $w --steps 3 --warmup 2 --no-cpu-baseline --no-others > $W/${w}_$c.out 2>&1
   done
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $W -o gj64_SQ1 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-others > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE -d $W -o gj64_SQ2 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-others > /dev/null 2>&1
-for w in gj64g gj128g chol1024 gj1024g gj256g; do
-B=""; [ $w = chol1024 ] && B="--batch 256"; [ $w = gj1024g ] && B="--batch 256"; [ $w = gj256g ] && B="--batch 3000"
+for w in gj64g gj128g gj192g chol144 chol1024 gj1024g gj256g; do
+B=""; [ $w = chol1024 ] && B="--batch 256"; [ $w = gj1024g ] && B="--batch 256"; [ $w = gj256g ] && B="--batch 3000"; [ $w = gj192g ] && B="--batch 5000"; [ $w = chol144 ] && B="--batch 10000"; [ $w = gj128g ] && B="--batch 25000"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $W -o ${w}_SQ1 -- python3 $R/bench.py --workload $w $B --steps 3 --warmup 2 --no-cpu-baseline --no-others > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_SALU -d $W -o ${w}_SQ2 -- python3 $R/bench.py --workload $w $B --steps 3 --warmup 2 --no-cpu-baseline --no-others > /dev/null 2>&1
 done
