@@ -130,9 +130,12 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_panel(T *W, int n, int
 
 // trailing update: W[I, J] -= L[I, K] L[J, K]^T for 64 x 64 tiles with jbeg <= J < jend, I >= J (rows up to row_end - 1);
 // K = the kcnt panel columns from kbeg on (one panel of 64, or the two panels of a pair: see launch_gp_blocked)
-template <class T>
+// LDL = true (the block-LDL^T path below): the J side of the product is read from the raw copy of the panel in Sraw (per item
+// BGP_PB columns of leading dimension ld, same row index as the working copy) instead of from the working copy itself.
+template <class T, bool LDL = false>
 __global__ __launch_bounds__(BGP_THREADS, MATINV_BGP_OCC) void matinv_bgp_update(T *W, int n, int ld, int row_end, int kbeg, int kcnt, int jbeg,
-                                                                 int jend, const int *status, unsigned gx, unsigned gy, unsigned nb)
+                                                                 int jend, const int *status, unsigned gx, unsigned gy, unsigned nb,
+                                                                 const T *Sraw = nullptr)
 {
     const XcdTile tile = xcd_tile_of(blockIdx.x, gx, gy, nb);
     if (!tile.valid) return;
@@ -153,7 +156,8 @@ __global__ __launch_bounds__(BGP_THREADS, MATINV_BGP_OCC) void matinv_bgp_update
     // slabs ahead was measured and lost: 130 VGPRs, three waves per SIMD instead of four, 1024^2 fp64 SPD inverse 23.7 ms against 21.4.
     const int lr = t & 63, lk = t >> 6;
     const bool in_i = i0 + lr < row_end, in_j = j0 + lr < jend;
-    const T *wi = w + (in_i ? i0 + lr : row_end - 1), *wj = w + (in_j ? j0 + lr : jend - 1);
+    const T *wi = w + (in_i ? i0 + lr : row_end - 1);
+    const T *wj = (LDL ? Sraw + item * (size_t)ld * BGP_PB : w) + (in_j ? j0 + lr : jend - 1);
     T pi[BGP_KS / 4], pj[BGP_KS / 4];
     auto fetch = [&](int ks) {
 #pragma unroll
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(BGP_THREADS, MATINV_BGP_OCC) void matinv_bgp_update
             const bool kin = k < pb;
             const size_t col = (size_t)(k0 + (kin ? k : pb - 1)) * ld;
             pi[x] = wi[col];  // raw: padding is zeroed when the slab is staged -- a select here would make the wave wait
-            pj[x] = wj[col];  // for the loads before the MFMAs they are meant to hide behind
+            pj[x] = wj[LDL ? (size_t)(kin ? k : pb - 1) * ld : col];  // for the loads before the MFMAs they are meant to hide behind
         }
     };
     fetch(0);
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(BGP_THREADS, MATINV_BGP_OCC) void matinv_bgp_update
 // wavefronts cost more than the matrix cores save. The lever is a wider panel, not the instruction.)
 template <class T>
 __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_finish(const T *W, const T *Es, T *out, int *info, int n, int ld,
-                                                                 const int *status)
+                                                                 const int *status, int drow)
 {
     __shared__ T part[BGP_THREADS / 64];
     const size_t item = blockIdx.x;
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_finish(const T *W, con
     const int bad = status[item];
     T s = 0;
     if (!bad)
-        for (int c = t; c < n; c += BGP_THREADS) s += w[(size_t)c * ld + n] * w[(size_t)c * ld + n + 1];
+        for (int c = t; c < n; c += BGP_THREADS) s += w[(size_t)c * ld + n] * w[(size_t)c * ld + drow];
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off);
     if ((t & 63) == 0) part[t >> 6] = s;
     __syncthreads();
@@ -217,6 +221,192 @@ __global__ __launch_bounds__(BGP_THREADS) void matinv_bgp_finish(const T *W, con
         for (int i = 0; i < BGP_THREADS / 64; ++i) q += part[i];
         out[item] = bad ? nan_of<T>() : (Es ? Es[item] - q : q);
         if (info) info[item] = bad;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Block LDL^T form of the same pipeline for LATENCY-BOUND launches (a handful of large items: the 512 / 1024 bins of the mixed queue,
+// r04). Measured on 8 x 1024^2 fp32, the dependent chain of 2 n / 64 launches waits for the panel kernel above: 50 us per launch, of
+// which the one-row-per-thread triangular solve is 34 us (2016 broadcast LDS reads per thread, four wavefronts on one LDS unit) and
+// the factorisation of the diagonal block 10 us; carrying the identity as border rows of that factorisation to get L11^-T (and the
+// solve as a product) cost as much as it saved (44 -> 40 us). Here no Cholesky factor is formed at all:
+//     S[I,J] <- A[I,J] - sum_{k<J} S[I,k] G_k S[J,k]^T,   G_k = S[k,k]^-1,   answer = sum_k S[a,k] G_k S[d,k]^T
+// (S[I,k] G_k S[J,k]^T = L[I,k] L[J,k]^T of the Cholesky form, so the Schur complements S are the same matrices). Per panel:
+//   matinv_bldl_panel   one workgroup per 64 rows below the diagonal block (border rows included). Wave 0 inverts the 64 x 64 block
+//                       with the symmetric MFMA sweep of the one-wavefront kernels (tile_kernels.inc: 16 block steps on 10 lower
+//                       tiles held in registers; non-positive pivot = not positive definite, reported with its column), every
+//                       wave then forms its 32 x 32 part of P = S[rows, k] G_k on the matrix cores, the S operand fetched from
+//                       global memory into MFMA operand registers BEFORE the sweep starts. P replaces the panel in place; the raw
+//                       panel S goes to a side buffer (the J side of the update) and the raw d-row to the extra row n + 2.
+//   matinv_bgp_update<T, true>   W[I,J] -= P[I,k] S[J,k]^T, the kernel above with its J operand read from the side buffer.
+// matinv_bgp_finish then takes the dot product of row n (P[a,:]) and row n + 2 (S[d,:]).
+template <class T>
+__device__ __forceinline__ void spd_invert64_wave(const T *S, int lds, T *Gs, int ldg, T *panel, int l, int &binfo)
+{
+    typedef TileGeo<T> G;
+    typedef typename G::vec4 vec4;
+    constexpr int NT = BGP_PB / 16;
+    int q = l >> 4, c = l & 15;
+    asm volatile("" : "+v"(q), "+v"(c));
+    vec4 acc[NT][NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+            if (tj > ti) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
+                const int hi = row > col ? row : col, lo = row > col ? col : row;
+                acc[ti][tj][r] = S[lo * lds + hi];  // the block is symmetric: only its lower triangle is stored
+            }
+        }
+    unsigned long long bad = 0;
+    T aop[NT], bop[NT];
+#pragma unroll
+    for (int kb = 0; kb < 4 * NT; ++kb) {
+        spd_panel_to_lds<NT, T>(panel, acc, kb, q, c);
+        wave_lds_sync();
+        PanelSolve<NT, true, T> ps;
+        ps.binfo = &binfo;
+#pragma unroll
+        for (int s = 0; s < PanelSolve<NT, true, T>::NSTAGE; ++s) ps.stage(s, panel, kb, q, c, aop, bop, bad);
+        spd_prep_operands<NT, T>(acc, bop, kb, q, c);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) {
+                if (tj > ti) continue;
+                acc[ti][tj] = G::mfma(aop[ti], bop[tj], acc[ti][tj]);
+            }
+        wave_lds_sync();
+    }
+    // acc = -S^-1 in the lower tiles (diagonal tiles complete): both triangles go to Gs
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+            if (tj > ti) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
+                Gs[row * ldg + col] = -acc[ti][tj][r];
+                if (tj < ti) Gs[col * ldg + row] = -acc[ti][tj][r];
+            }
+        }
+}
+
+// (two waves per SIMD = at most 256 registers, all of them VGPRs: built for one wave per SIMD hipcc puts the fp32 accumulators of the
+// sweep into AGPRs and its AGPR-form v_mfma_f32 computes garbage from the second block step on -- ROCm 7.2.0, see matinv_spd_tile_f32)
+template <class T>
+__global__ __launch_bounds__(BGP_THREADS, 2) void matinv_bldl_panel(T *W, T *Sraw, int n, int ld, int row_end, int k0, int *status)
+{
+    typedef TileGeo<T> G;
+    constexpr int LD = BGP_PB + 1;
+    __shared__ T Sd[BGP_PB * LD];  // the diagonal block, column-major Sd[c * LD + r], lower triangle
+    __shared__ T Gs[BGP_PB * LD];  // its inverse, both triangles
+    __shared__ T panel[4 * BGP_PB];
+    __shared__ int sh_bad;
+    const size_t item = blockIdx.y;
+    const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB, t = threadIdx.x;
+    T *w = W + item * (size_t)ld * n;
+    T *sraw = Sraw + item * (size_t)ld * BGP_PB;
+    if (status[item] != 0) return;  // an earlier panel found a non-positive pivot
+    const int wv = t >> 6, q = (t >> 4) & 3, c = t & 15;
+    // this wavefront's rows of the panel (the I side of the product): 2 x 16 rows, all 64 panel columns, in MFMA operand layout
+    const int r0 = k0 + pb + blockIdx.x * BGP_TILE + 32 * (wv & 1) + c;
+    T b[2][BGP_PB / 4];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int r = r0 + 16 * ti;
+        const T *wr = w + (r < row_end ? r : row_end - 1);
+#pragma unroll
+        for (int k4 = 0; k4 < BGP_PB / 4; ++k4) {
+            const int k = 4 * k4 + q;
+            b[ti][k4] = wr[(size_t)(k0 + (k < pb ? k : pb - 1)) * ld];  // clamped address: padding columns meet zeros of G
+        }
+    }
+    for (int e = t; e < BGP_PB * BGP_PB; e += BGP_THREADS) {
+        const int cc = e / BGP_PB, r = e - cc * BGP_PB;
+        // lower triangle; ragged last panel: identity padding
+        Sd[cc * LD + r] = (r < pb && cc < pb) ? ((r >= cc) ? w[(size_t)(k0 + cc) * ld + k0 + r] : (T)0) : (T)(r == cc);
+    }
+    if (t == 0) sh_bad = 0;
+    __syncthreads();
+    if (wv == 0) {  // wave-uniform
+        int binfo = 0;
+        spd_invert64_wave<T>(Sd, LD, Gs, LD, panel, t, binfo);
+        if (t == 0) sh_bad = binfo;
+    }
+    __syncthreads();
+    const int bad = sh_bad;
+    if (bad) {  // block-uniform, and the same in every workgroup of this item
+        if (t == 0 && blockIdx.x == 0) status[item] = k0 + bad;
+        return;
+    }
+    // P[I][J] = sum_k S[I][k] G[k][J]; computed transposed as in slab_mma (the MFMA's A operand carries the J side), so that a lane
+    // group holds 16 consecutive rows I of one column J
+    const int jb = 32 * (wv >> 1) + c;
+    typename G::vec4 acc[2][2] = {};
+#pragma unroll
+    for (int k4 = 0; k4 < BGP_PB / 4; ++k4) {
+        const int k = 4 * k4 + q;
+        const T a0 = Gs[jb * LD + k], a1 = Gs[(jb + 16) * LD + k];
+        acc[0][0] = G::mfma(a0, b[0][k4], acc[0][0]);
+        acc[0][1] = G::mfma(a0, b[1][k4], acc[0][1]);
+        acc[1][0] = G::mfma(a1, b[0][k4], acc[1][0]);
+        acc[1][1] = G::mfma(a1, b[1][k4], acc[1][1]);
+    }
+    // the raw panel: the J side of this panel's update, and the raw d-row for the final dot product
+    if ((wv >> 1) == 0) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int I = r0 + 16 * ti;
+#pragma unroll
+            for (int k4 = 0; k4 < BGP_PB / 4; ++k4) {
+                const int k = 4 * k4 + q;
+                if (I < row_end && k < pb) {
+                    if (I < n) sraw[(size_t)k * ld + I] = b[ti][k4];
+                    if (I == n + 1) w[(size_t)(k0 + k) * ld + n + 2] = b[ti][k4];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int J = 32 * (wv >> 1) + 16 * tj + G::trow(r, q), I = r0 + 16 * ti;
+                if (I < row_end && J < pb) w[(size_t)(k0 + J) * ld + I] = acc[tj][ti][r];
+            }
+}
+
+// Few large items: the launch chain is what takes the time. Measured (fused mean, ms per batch, Cholesky form / this one): fp32 8 x 1024^2
+// 0.97 / 0.50, 32 x 512^2 0.50 / 0.26, 64 x 1024^2 1.44 / 1.12, 128 x 512^2 0.63 / 0.46, 512 x 200^2 0.33 / 0.24; fp64 8 x 1024^2 1.15 /
+// 0.69, 64 x 1024^2 1.87 / 1.82; beyond about a thousand 64-row blocks per batch the paired rank-128 updates of the Cholesky form win
+// (fp32 762 x 512^2 1.78 / 2.14, 256 x 1024^2 3.11 / 3.82). MATINV_BGP_LDL=0 / 1: never / always.
+static bool bgp_ldl_pays(int n, unsigned b)
+{
+    static const int mode = [] { const char *s = getenv("MATINV_BGP_LDL"); return s ? atoi(s) : -1; }();
+    if (mode == 0 || mode == 1) return mode == 1;
+    return (size_t)b * ((size_t)(n + BGP_TILE - 1) / BGP_TILE) <= 1024;
+}
+
+template <class T>
+static void bgp_ldl_chain(T *W, T *Sraw, int n, int ld, unsigned b, int *status, hipStream_t stream)
+{
+    const int rows = n + 2;
+    for (int k0 = 0; k0 < n; k0 += BGP_PB) {
+        const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
+        const unsigned chunks = (unsigned)((rows - (k0 + pb) + BGP_TILE - 1) / BGP_TILE);  // >= 1: the border rows
+        hipLaunchKernelGGL(matinv_bldl_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, Sraw, n, ld, rows, k0, status);
+        const int k1 = k0 + pb;
+        if (k1 >= n) break;
+        const unsigned gx = (unsigned)((n - k1 + BGP_TILE - 1) / BGP_TILE), gy = (unsigned)((rows - k1 + BGP_TILE - 1) / BGP_TILE);
+        hipLaunchKernelGGL((matinv_bgp_update<T, true>), dim3(xcd_tile_grid(gx, gy, b)), dim3(BGP_THREADS), 0, stream, W, n, ld, rows, k0, pb,
+                           k1, n, status, gx, gy, b, Sraw);
     }
 }
 
@@ -268,7 +458,8 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
 {
     if (n < 1 || n > 4096) return hipErrorInvalidValue;
     if (batch == 0) return hipSuccess;
-    const int rows = n + 2, ld = bgp_ld<T>(rows);
+    const bool ldl = bgp_ldl_pays(n, (unsigned)(batch < 65535 ? batch : 65535));
+    const int rows = n + 2, ld = bgp_ld<T>(ldl ? rows + 1 : rows);  // block LDL^T: one more row (the raw d-row)
     // chunks: grid.y / grid.z limit and a bounded workspace
     size_t chunk = blocked_workspace_cap() / ((size_t)ld * n * sizeof(T));
     if (chunk < 1) chunk = 1;
@@ -280,6 +471,11 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
     if (e != hipSuccess) return e;
     e = scratch_alloc(reinterpret_cast<void **>(&status), chunk * sizeof(int), stream);
     if (e != hipSuccess) { (void)scratch_free(W, stream); return e; }
+    T *Sraw = nullptr;
+    if (ldl) {
+        e = scratch_alloc(reinterpret_cast<void **>(&Sraw), chunk * (size_t)ld * BGP_PB * sizeof(T), stream);
+        if (e != hipSuccess) { (void)scratch_free(W, stream); (void)scratch_free(status, stream); return e; }
+    }
     for (size_t first = 0; first < batch; first += chunk) {
         const unsigned b = (unsigned)((batch - first < chunk) ? batch - first : chunk);
         const T *a_ = As + first * n, *B_ = Bs + first * (size_t)n * n, *c_ = Cs + first * n, *d_ = Ds ? Ds + first * n : nullptr;
@@ -287,14 +483,17 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
         // Panels of 64 columns applied in PAIRS: after the first panel only the next 64 columns are updated (narrow launch),
         // the second panel is factored, and everything behind the pair takes both panels in ONE rank-128 update -- the same
         // number of launches as panel / update per 64 columns, half the read-modify-write traffic on the trailing matrix.
-        for (int k0 = 0; k0 < n; k0 += 2 * BGP_PB) {
-            bgp_pair<T>(W, n, ld, k0, rows, rows, b, status, stream);
+        if (ldl) {
+            bgp_ldl_chain<T>(W, Sraw, n, ld, b, status, stream);
+        } else {
+            for (int k0 = 0; k0 < n; k0 += 2 * BGP_PB) bgp_pair<T>(W, n, ld, k0, rows, rows, b, status, stream);
         }
         hipLaunchKernelGGL(matinv_bgp_finish<T>, dim3(b), dim3(BGP_THREADS), 0, stream, W, (Ds || !Es) ? nullptr : Es + first,
-                           out + first, info ? info + first : nullptr, n, ld, status);
+                           out + first, info ? info + first : nullptr, n, ld, status, ldl ? n + 2 : n + 1);
     }
     e = hipGetLastError();
     hipError_t e2 = scratch_free(W, stream), e3 = scratch_free(status, stream);
+    if (Sraw) (void)scratch_free(Sraw, stream);
     return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
 }
 template hipError_t launch_gp_blocked<double>(int, const double *, const double *, const double *, const double *,
