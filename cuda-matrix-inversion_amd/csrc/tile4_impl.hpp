@@ -278,6 +278,9 @@ __global__ __launch_bounds__(64 * T4_WAVES, T4_WAVES > 4 ? 1 : (T4_WAVES <= 2 ? 
 // (r03, measured and not kept: fp32 9 ... 12 tiles per dimension with TWO tile columns per wave and (NT + 1) / 2 waves, three waves per
 // SIMD so that two matrices fit a CU: 130^2 / 160^2 4.85e6 / 3.76e6 inv/s against 4.95e6 / 3.83e6, and 176^2 / 192^2 1.9e6 / 1.65e6
 // against 3.0e6 / 2.66e6 -- 200+ B of scratch there, and every wave's redundant panel solve now serves two columns' worth of waiting)
+// (r04, measured and not kept: fp64 9 ... 11 tiles per dimension on FOUR waves of three tile columns, one wave per SIMD on VGPRs + AGPRs
+// (498 registers, none spilled at 9 x 9; 15 / 137 spilled at 10 x 10 / 12 x 12): 130^2 2.9e6 inv/s against 3.3e6 with one wave per tile
+// column, 160^2 2.1e6 against 2.5e6, 176^2 1.2e6 against 2.0e6 -- fewer redundant panel solves, but nothing left to overlap them with.)
 constexpr int t4_waves(bool f64, int nt) { return nt > 8 ? nt : (f64 ? (nt <= 6 ? 2 : 4) : (nt <= 5 ? 1 : (nt <= 7 ? 2 : 4))); }
 constexpr int t4_wide_limit(bool f64) { return f64 ? 192 : 256; }
 
