@@ -168,18 +168,23 @@ def mixed_result(args, api, device, rank, world):
         chunks += [(n, v[0, i:i + CH].reshape(-1), B[i:i + CH].reshape(-1), v[1, i:i + CH].reshape(-1), v[2, i:i + CH].reshape(-1))
                    for i in range(0, cnt, CH)]
     chunks = [chunks[i] for i in torch.randperm(len(chunks), generator=torch.Generator().manual_seed(1)).tolist()]
-    # `inflight` flushes may be in progress at once (MATINV_MIX_INFLIGHT, default 2): consecutive steps alternate between that
-    # many queues, each on its own stream, so the dependent-launch chain of one step's large bins (8 x 1024^2 = 34 launches that
-    # leave most of the chip idle) runs beside the next step's. Every step still submits and flushes ALL of its items, results
-    # are complete at the synchronisation that ends the timed region; 1 = strictly one flush after the other (the r01/r02 figure).
-    # Stream placement (r04): a queue binds its two chain streams to consecutive hardware queues when it is created
-    # (matinv_queue_create), so the queues built here -- one right after the other -- put their four chains on four different
-    # hardware queues whatever the process did before. r03 left the binding to the first flush and got 0.72 or 0.95 ms per step
-    # depending on how many streams had been used before; it tried four stream sets and reported the best. No selection any more.
-    inflight = max(1, int(os.environ.get("MATINV_MIX_INFLIGHT", str(getattr(args, "inflight", 2)))))
+    # `inflight` flushes may be in progress at once (MATINV_MIX_INFLIGHT, default 3): consecutive steps alternate between that
+    # many queues, each flush on its queue's own stream, so the dependent-launch chain of one step's large bins (8 x 1024^2 = 33
+    # launches that leave most of the chip idle) runs beside the next step's. Every step still submits and flushes ALL of its items,
+    # results are complete at the synchronisation that ends the timed region; 1 = strictly one flush after the other.
+    # Stream placement (r04): a queue creates exactly two streams, one after the other; HIP deals streams onto its four hardware
+    # queues in creation order, so queues built one right after the other never put two chains on one hardware queue (r03's queue
+    # created four streams each: the chains of two queues always collided unless streams created in between shifted them; it tried
+    # four stream sets and reported the best). No selection: 2 in flight 0.60 ms per step, 3 in flight 0.53, 4 in flight 0.54.
+    inflight = max(1, int(os.environ.get("MATINV_MIX_INFLIGHT", str(getattr(args, "inflight", 3)))))
     def make_set():
         qs_ = [bq.SizeBinnedQueue(device=device) for _ in range(inflight)]
-        st_ = [torch.cuda.Stream(device=device) for _ in range(inflight)] if inflight > 1 else [torch.cuda.current_stream(device)]
+        # every flush is issued on its queue's OWN stream (matinv_queue_stream): a flush then lives on the two hardware queues its queue
+        # bound when it was created, whatever other streams the process has used (MATINV_MIX_CALLER_STREAMS=1: torch streams, as r03)
+        if os.environ.get("MATINV_MIX_CALLER_STREAMS") == "1":
+            st_ = [torch.cuda.Stream(device=device) for _ in range(inflight)] if inflight > 1 else [torch.cuda.current_stream(device)]
+        else:
+            st_ = [q_.home_stream(torch.float32) for q_ in qs_]
         return {"qs": qs_, "streams": st_, "turn": 0}
 
     cur = make_set()
@@ -196,7 +201,8 @@ def mixed_result(args, api, device, rank, world):
         host_s[0] += time.perf_counter() - t_  # submit + flush return when everything is ENQUEUED: the host share of a step
         return out
 
-    placement = "bound at matinv_queue_create (consecutive hardware queues); no trials"
+    placement = ("caller streams" if os.environ.get("MATINV_MIX_CALLER_STREAMS") == "1" else
+                 "every flush on its queue's own stream (matinv_queue_stream): two hardware queues per queue, bound at matinv_queue_create; no trials")
     q = cur["qs"][0]
 
     import torch.distributed as tdist
@@ -615,7 +621,7 @@ def main():
         # BASELINE configs[4] on this GPU (the C queue), a short run of the same code path as --workload mixed
         keys = ("value", "unit", "ms_per_step", "steps", "dtype", "host_ms_per_step", "host_share", "means_finite", "per_bin", "config")
         m1 = mixed_result(argparse.Namespace(steps=10, warmup=3, inflight=1), api, device, rank, world)
-        m2 = mixed_result(argparse.Namespace(steps=20, warmup=4, inflight=2), api, device, rank, world)
+        m2 = mixed_result(argparse.Namespace(steps=20, warmup=4, inflight=3), api, device, rank, world)
         mixed = {k: m2[k] for k in keys}
         mixed["one_flush_at_a_time"] = {k: m1[k] for k in ("value", "ms_per_step", "host_ms_per_step", "host_share")}
 

@@ -35,7 +35,7 @@ NATIVE_NAMES = [
     "matinv_variance_batched_host", "matinv_last_error",
     "matinv_abi_version", "matinv_release_cache", "matinv_stream_retire", "matinv_batched_malloc", "matinv_batched_free", "matinv_memcpy_2d",
     "matinv_device_synchronize", "matinv_tile_stats", "matinv_queue_create", "matinv_queue_submit", "matinv_queue_submit_chunks", "matinv_queue_pending",
-    "matinv_queue_bins", "matinv_queue_flush", "matinv_queue_destroy", "matinv_queue_last_error",
+    "matinv_queue_bins", "matinv_queue_flush", "matinv_queue_destroy", "matinv_queue_last_error", "matinv_queue_stream",
     "matinv_set_gj_policy", "matinv_device_count", "matinv_shard_range", "matinv_inverse_batched_host_multi", "matinv_comm_unique_id",
     "matinv_comm_init_rank", "matinv_comm_destroy", "matinv_allgather_shards", "matinv_allgather_local", "matinv_allgather_local_after", "matinv_debug_rejects",
 ]
@@ -125,6 +125,8 @@ def lib() -> ctypes.CDLL:
     L.matinv_queue_bins.argtypes = [vp, vp, ci]
     L.matinv_queue_flush.restype = ci
     L.matinv_queue_flush.argtypes = [vp, vp, vp, vp]
+    L.matinv_queue_stream.restype = vp
+    L.matinv_queue_stream.argtypes = [vp]
     L.matinv_queue_destroy.restype = ci
     L.matinv_queue_destroy.argtypes = [vp]
     L.matinv_queue_last_error.restype = ctypes.c_char_p

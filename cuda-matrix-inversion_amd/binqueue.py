@@ -62,6 +62,8 @@ class SizeBinnedQueue:
         self._keep = []   # tensors of the pending chunks (the C queue holds raw pointers)
         self._tickets = 0
         self._want_var = True
+        self._home_ptr = None  # matinv_queue_stream, once asked for
+        self._held = []        # (event, chunks) of flushes issued on it
 
     def _handle(self, dtype):
         import torch
@@ -76,6 +78,15 @@ class SizeBinnedQueue:
         elif dtype != self._dtype:
             raise TypeError("one queue serves one dtype")
         return self._q
+
+    def home_stream(self, dtype=None):
+        """The C queue's own stream as a torch stream (matinv_queue_stream): submitting and flushing inside
+        `with torch.cuda.stream(q.home_stream())` keeps a flush on the queue's two hardware queues (include/matinv.h). The queue is
+        created here if it does not exist yet (dtype: torch.float32 unless given)."""
+        import torch
+        q = self._handle(dtype or self._dtype or torch.float32)
+        self._home_ptr = int(_lib.lib().matinv_queue_stream(q))
+        return torch.cuda.ExternalStream(self._home_ptr, device=self.device)
 
     def __del__(self):
         try:
@@ -172,9 +183,17 @@ class SizeBinnedQueue:
         finally:
             # the chunks must outlive the asynchronous launches (also those of a flush that failed half way): their memory is
             # returned to torch's caching allocator only after the current stream has passed this point
-            for ts in self._keep:
-                for t in ts:
-                    t.record_stream(stream)
+            if stream.cuda_stream == self._home_ptr:
+                # the queue's own stream: it dies with the queue, so no tensor may carry a record_stream() of it (the caching
+                # allocator would record an event on the dead stream when such a tensor is freed) -- hold the chunks until an
+                # event recorded behind this flush has completed
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                self._held = [(e_, k_) for (e_, k_) in self._held if not e_.query()] + [(ev, self._keep)]
+            else:
+                for ts in self._keep:
+                    for t in ts:
+                        t.record_stream(stream)
             self._keep = []
             self._tickets = 0
             self._want_var = True

