@@ -704,6 +704,7 @@ int matinv_release_cache(void)
     if (rc) return rc;
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail_hip(e, "release cache");
+    blocked_gp_release_graphs();
     scratch_release_device();
     return MATINV_OK;
 }

@@ -19,6 +19,7 @@ int fail_hip(hipError_t e, const char *what);
 hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t stream);
 hipError_t scratch_free(void *p, hipStream_t stream);
 void scratch_retire_stream(hipStream_t stream);  // after synchronising a stream that is about to be destroyed
+void blocked_gp_release_graphs();                // the cached launch-chain graphs of blocked_gp_kernels.hip (they hold scratch pointers)
 void scratch_release_device();                   // after hipDeviceSynchronize: hipFree everything not in use
 
 // Where matrix k of a batch lives: either base + k*stride, or table[k] (the reference's

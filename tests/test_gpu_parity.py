@@ -552,6 +552,47 @@ def test_pipeline_large_n_blocked(n, batch, dtype):
     assert info_m.cpu().tolist() == [0] * (batch - 1) + [n // 2 + 1] == info_v.cpu().tolist()
 
 
+@pytest.mark.parametrize("n,batch,dtype", [(200, 5, "f64"), (512, 3, "f32")])
+def test_blocked_pipeline_graph_replay_follows_the_data(n, batch, dtype):
+    """A latency-bound call of the blocked fused pipeline that repeats its pointers is replayed as a HIP graph from the third call on
+    (blocked_gp_kernels.hip): the replay must read the buffers as they are NOW (values changed in place between the calls), report a
+    matrix that stopped being positive definite, and agree bit for bit with the direct launches of the first call."""
+    rng = np.random.default_rng(n)
+    np_t = np.float64 if dtype == "f64" else np.float32
+    B = spd_batch(n, batch, seed=n + 7)
+    va, vc, vd = (rng.random(batch * n) for _ in range(3))
+    t = [dev(x.astype(np_t)) for x in (va, B, vc, vd)]
+    out = torch.empty(batch, dtype=t[0].dtype, device="cuda")
+    info = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    tol = 1e-10 if dtype == "f64" else 2e-4
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        first = None
+        for call in range(5):
+            api.calcluateMean(n, t[0], t[1], t[2], t[3], Means=out, info=info)
+            st.synchronize()
+            if call == 0:
+                first = out.clone()
+            assert torch.equal(out, first) and int(info.abs().sum()) == 0
+        want = oracle.mean_batched(va, B, vc, vd, n)
+        assert np.abs(out.cpu().numpy().astype(np.float64) - want).max() < tol * max(1.0, np.abs(want).max())
+        # new values in the same buffers
+        va2 = rng.random(batch * n)
+        B2 = spd_batch(n, batch, seed=n + 8)
+        t[0].copy_(dev(va2.astype(np_t)))
+        t[1].copy_(dev(B2.astype(np_t)))
+        api.calcluateMean(n, t[0], t[1], t[2], t[3], Means=out, info=info)
+        st.synchronize()
+        want2 = oracle.mean_batched(va2, B2, vc, vd, n)
+        assert np.abs(out.cpu().numpy().astype(np.float64) - want2).max() < tol * max(1.0, np.abs(want2).max())
+        # and an item that is no longer positive definite
+        t[1].view(batch, n, n)[1, n // 3, n // 3] = -1e3
+        t[2].view(batch, n)[1, n // 3] = 0.0
+        api.calcluateMean(n, t[0], t[1], t[2], t[3], Means=out, info=info)
+        st.synchronize()
+        assert info.cpu().tolist() == [0, n // 3 + 1] + [0] * (batch - 2) and bool(torch.isnan(out[1]))
+
+
 @pytest.mark.parametrize("n,batch,dtype", [(200, 530, "f64"), (257, 340, "f32"), (333, 240, "f64")])
 def test_blocked_cholesky_paths_panel_pairs(n, batch, dtype):
     """Batches large enough for the blocked Cholesky path to apply its 64-column panels in PAIRS (narrow update, second panel,

@@ -41,6 +41,7 @@ SETTINGS = [
     ({"MATINV_BGP_PAIRS": "1"}, ["chol:f64:320:6", "mean:f64:256:6"]),
     # fused pipeline, blocked path: Cholesky form forced on a few items / block-LDL^T form forced on many
     ({"MATINV_BGP_LDL": "0"}, ["mean:f32:512:8", "variance:f64:200:20", "mean:f64:1000:3"]),
+    ({"MATINV_BGP_GRAPH": "0"}, ["mean:f32:512:8", "variance:f64:200:20"]),
     ({"MATINV_BGP_LDL": "1"}, ["mean:f32:200:600", "variance:f64:320:300", "mean:f32:190:40", "mean:f64:1024:20"]),
     # host-pointer entry points: chunked upload / compute / download overlap forced on a small batch, and off
     ({"MATINV_HOST_PIPELINE": "1"}, ["host:f64:64:3000", "host:f32:32:5000"]),
