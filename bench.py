@@ -426,13 +426,14 @@ def main():
     x.copy_(a)
     copy_gbs = 2 * a.numel() * a.element_size() / (float(np.median(time_launches(lambda: x.copy_(a), 9))) * 1e-3) / 1e9
 
+    # HIP events on the stream the kernel is launched on (api passes torch's current stream to the C ABI). Created BEFORE the warm-up,
+    # and the check of the warm-up's info codes is left until after the timed steps: the card falls back towards its idle clocks
+    # within a millisecond or two without work and takes some 20 ms of load to come back (the same 20 steps measured 1.62 ms per step
+    # behind a 2 ms gap of host work and 1.48 ms in a long run) -- between warm-up and timed region there is now only the prescribed
+    # barrier + synchronisation
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    assert int(info[:batch].abs().sum()) == 0, "synthetic batch reported singular matrices"
-
-    # HIP events on the stream the kernel is launched on (api passes torch's current stream to the C ABI)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -445,7 +446,9 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    step_ms = [s.elapsed_time(e) for s, e in ev]
+    kern_ms = float(np.mean(step_ms))
+    assert int(info[:batch].abs().sum()) == 0, "synthetic batch reported singular matrices"
 
     gather = None
     if dist is not None:
@@ -631,6 +634,7 @@ def main():
         roof, roof_other = rooflines(algo_name, n, batch, kern_ms)
         traffic, traffic_src = load_traffic(kname, n, batch)
         roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "kernel_ms": kern_ms,
+                     "kernel_ms_first_min_last": [step_ms[0], min(step_ms), step_ms[-1]],
                      "units_per_launch": batch, "per": "GPU"})
         hbm_side = roof if roof["bound"] == "hbm" else roof_other
         hbm_side["guide_copy_GBs"] = HBM_GUIDE_ACHIEVABLE_GBS
