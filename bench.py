@@ -168,15 +168,14 @@ def mixed_result(args, api, device, rank, world):
         chunks += [(n, v[0, i:i + CH].reshape(-1), B[i:i + CH].reshape(-1), v[1, i:i + CH].reshape(-1), v[2, i:i + CH].reshape(-1))
                    for i in range(0, cnt, CH)]
     chunks = [chunks[i] for i in torch.randperm(len(chunks), generator=torch.Generator().manual_seed(1)).tolist()]
-    # `inflight` flushes may be in progress at once (MATINV_MIX_INFLIGHT, default 3): consecutive steps alternate between that
-    # many queues, each flush on its queue's own stream, so the dependent-launch chain of one step's large bins (8 x 1024^2 = 33
-    # launches that leave most of the chip idle) runs beside the next step's. Every step still submits and flushes ALL of its items,
-    # results are complete at the synchronisation that ends the timed region; 1 = strictly one flush after the other.
-    # Stream placement (r04): a queue creates exactly two streams, one after the other; HIP deals streams onto its four hardware
-    # queues in creation order, so queues built one right after the other never put two chains on one hardware queue (r03's queue
-    # created four streams each: the chains of two queues always collided unless streams created in between shifted them; it tried
-    # four stream sets and reported the best). No selection: 2 in flight 0.60 ms per step, 3 in flight 0.53, 4 in flight 0.54.
-    inflight = max(1, int(os.environ.get("MATINV_MIX_INFLIGHT", str(getattr(args, "inflight", 3)))))
+    # `inflight` flushes may be in progress at once (default 2; MATINV_MIX_INFLIGHT overrides it in --workload mixed): consecutive steps
+    # alternate between that many queues, each flush on its queue's own stream, so the dependent-launch chain of one step's large bins
+    # (8 x 1024^2 = 33 launches that leave most of the chip idle) runs beside the next step's. Every step still submits and flushes ALL
+    # of its items, results are complete at the synchronisation that ends the timed region; 1 = strictly one flush after the other.
+    # Stream placement (r04): a queue owns two streams with a hardware queue each (csrc/queue.hip), so the figure no longer depends on
+    # the streams the process created before (r03 tried four stream sets and reported the best). 2 in flight 0.47 ms per step, 3 in
+    # flight 0.69 (six hardware queues at work).
+    inflight = max(1, int(getattr(args, "inflight", 0) or os.environ.get("MATINV_MIX_INFLIGHT", "2")))
     def make_set():
         qs_ = [bq.SizeBinnedQueue(device=device) for _ in range(inflight)]
         # every flush is issued on its queue's OWN stream (matinv_queue_stream): a flush then lives on the two hardware queues its queue
@@ -207,7 +206,9 @@ def mixed_result(args, api, device, rank, world):
 
     import torch.distributed as tdist
     multi = world > 1 and tdist.is_initialized()
-    for _ in range(max(1, args.warmup)):
+    # warm-up: every queue has to have flushed three times before the steady state is reached (the library replays the launch chain of a
+    # large-n group as a HIP graph from its third appearance on: first sighting, capture, replay)
+    for _ in range(max(1, args.warmup, 3 * inflight)):
         step()
     if multi:
         tdist.barrier()
@@ -624,7 +625,7 @@ def main():
         # BASELINE configs[4] on this GPU (the C queue), a short run of the same code path as --workload mixed
         keys = ("value", "unit", "ms_per_step", "steps", "dtype", "host_ms_per_step", "host_share", "means_finite", "per_bin", "config")
         m1 = mixed_result(argparse.Namespace(steps=10, warmup=3, inflight=1), api, device, rank, world)
-        m2 = mixed_result(argparse.Namespace(steps=20, warmup=4, inflight=3), api, device, rank, world)
+        m2 = mixed_result(argparse.Namespace(steps=20, warmup=4, inflight=2), api, device, rank, world)
         mixed = {k: m2[k] for k in keys}
         mixed["one_flush_at_a_time"] = {k: m1[k] for k in ("value", "ms_per_step", "host_ms_per_step", "host_share")}
 

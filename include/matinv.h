@@ -203,12 +203,13 @@ int matinv_queue_submit_chunks(matinv_queue *q, size_t chunks, const int *n, con
 int matinv_queue_pending(const matinv_queue *q, size_t *items, size_t *per_bin);
 int matinv_queue_bins(const matinv_queue *q, int *bins, int cap);
 int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *stream);
-/* The queue's own stream (a hipStream_t). A queue creates exactly two streams, one after the other, and HIP deals the streams of a
- * process onto its four hardware queues in creation order; a stream that waits for a launch chain blocks whatever shares its hardware
- * queue. Submitting and flushing ON this stream (pass it as `stream`) keeps a flush on the queue's two hardware queues: the bins other
- * than the largest run in it, the chain of the largest bin beside it. Queues created one after the other then overlap their flushes
- * whatever other streams the process has used (bench.py, mixed workload: 0.53 ms per step with three flushes in flight, 0.70 with one;
- * on caller-created streams 0.68 - 0.73). The caller orders its own work after the flush with an event recorded on this stream. */
+/* The queue's own stream (a hipStream_t). A queue owns two streams that each have a hardware queue to themselves (HIP multiplexes
+ * ordinary streams onto four shared hardware queues, placed by the history of the process). Submitting and flushing ON this stream
+ * (pass it as `stream`) keeps a flush on those two hardware queues: the bins other than the largest run in it, the chain of the
+ * largest bin beside it. Two queues used alternately then overlap their flushes whatever other streams the process has created
+ * (bench.py, mixed workload: 0.47 ms per step with two flushes in flight, 0.71 one at a time; on caller-created streams 0.53 - 0.73
+ * depending on that history). Keep to two such queues in flight (three: 0.69 ms). These are blocking streams (they synchronise with
+ * the null stream); the caller orders its own work after the flush with an event recorded on this stream. */
 void *matinv_queue_stream(matinv_queue *q);
 int matinv_queue_destroy(matinv_queue *q);
 const char *matinv_queue_last_error(const matinv_queue *q);
