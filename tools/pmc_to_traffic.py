@@ -34,23 +34,22 @@ for (wl, kern), v in vals.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         tot = 2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]
         if kern not in best or tot > best[kern][0]:
-            best[kern] = (tot, v)
-for kern, (_, v) in best.items():
+            best[kern] = (tot, v, wl)
+for kern, (_, v, wl) in best.items():
     if "worklist" in kern:
         continue
-    m = re.search(r"<(?:double, )?(\d+)", kern)
+    m = re.search(r"(\d+)", wl)  # the workload names its n: gj64, chol144, gj192g ...
     if not m:
         continue
+    n, b = int(m.group(1)), batch  # (the FETCH_SIZE / WRITE_SIZE passes all run the default batch)
     rd, wr = 2.0 * v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
-    n = {"matinv_gj_tile_f64": 16, "matinv_spd_tile_f64": 16, "matinv_gj_tile4_f64": 16, "matinv_gj_tilep_f64": 16,
-         "matinv_gj_tilep4_f64": 16, "matinv_gj_tilep3_f64": 16, "matinv_gj_tilepb_f64": 16, "matinv_gj_tilepw_f64": 16}.get(kern.split("<")[0], 1) * int(m.group(1))
-    if (rd + wr) < 0.1 * batch * 2 * n * n * 8:
+    if (rd + wr) < 0.1 * b * 2 * n * n * 8:
         continue  # a launch that moved (almost) nothing: an empty work-list pass, not this kernel's job
     table[f"{kern}|n={n}"] = rd + wr
-    table[f"{kern}|n={n}|detail"] = {"batch": batch, "read_bytes": rd, "write_bytes": wr,
-                                     "algorithmic_bytes": batch * 2 * n * n * 8,
-                                     "traffic_over_algorithmic": (rd + wr) / (batch * 2 * n * n * 8), "source": os.path.basename(src)}
+    table[f"{kern}|n={n}|detail"] = {"batch": b, "read_bytes": rd, "write_bytes": wr, "workload": wl,
+                                     "algorithmic_bytes": b * 2 * n * n * 8,
+                                     "traffic_over_algorithmic": (rd + wr) / (b * 2 * n * n * 8), "source": os.path.basename(src)}
 json.dump(table, open(path, "w"), indent=1, sort_keys=True)
 for k, v in table.items():
     if not k.endswith("detail"):
-        print(k, v, table[k + "|detail"]["traffic_over_algorithmic"])
+        print(k, v, round(table[k + "|detail"]["traffic_over_algorithmic"], 4))
