@@ -24,7 +24,7 @@ for ln in open(src):
     wl, kern = f[0].rsplit("_", 2)[0], f[4].strip()
     # a natural-order kernel seen in a GENERAL workload's pass rejected every matrix there (it read them and wrote nothing):
     # not its job -- only the pivoting kernels are taken from those passes
-    if wl.endswith("g") and "tilep" not in kern:
+    if wl.endswith("g") and "tilep" not in kern and "tileq" not in kern:
         continue
     vals.setdefault((wl, kern), {})[f[1]] = float(f[2])
 path = os.path.join(os.path.dirname(src), "traffic.json")
