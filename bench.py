@@ -280,7 +280,7 @@ def run_mixed(args, api, device, rank, world):
 def mfma_flops_per_inversion(algo_name, n):
     """fp64 flops the MFMA tile kernels issue per matrix (None for the families without MFMA): a blocked sweep of 4*NT
     rank-4 steps over NT^2 tiles (Gauss-Jordan: all tiles = 2 n^3 flop) or over the NT(NT+1)/2 lower tiles (SPD sweep on one or
-    two wavefronts per matrix: n <= 176 in fp64; beyond, one wavefront per tile column sweeps all tiles), 2048 flop per MFMA.
+    two or three wavefronts per matrix, n <= 192 in fp64), 2048 flop per MFMA.
     Blocked two-level Gauss-Jordan (n >= 384): 2 n^3. Blocked SPD inverse (n > 192; update and Y Y^T product on the matrix
     cores): n^3 -- factor, triangular inverse and product at n^3 / 3 each (the 64 x 64 tile granularity issues more)."""
     if n > 192 and algo_name == "gj":
@@ -292,7 +292,7 @@ def mfma_flops_per_inversion(algo_name, n):
     if n <= 16 or n > 192:
         return None
     nt = (n + 15) // 16
-    tiles = nt * nt if (algo_name == "gj" or n > 176) else nt * (nt + 1) // 2
+    tiles = nt * nt if algo_name == "gj" else nt * (nt + 1) // 2
     # block steps actually executed: the all-padding 4-column blocks of the last tile column are skipped (fp64: ceil(rem / 4))
     steps = 4 * (nt - 1) + (n - 16 * (nt - 1) + 3) // 4
     return steps * tiles * 2048

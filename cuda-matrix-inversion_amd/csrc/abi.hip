@@ -532,7 +532,7 @@ int gp_dispatch(int n, const void *a, const void *B, const void *c, const void *
         if (er != hipSuccess) return fail_hip(er, "kernel launch");
         return MATINV_OK;
     }
-    // MFMA tile kernels, one or two wavefronts per item, lower tiles only: fp64 112 < n <= 176 on two wavefronts (spd_tile2_impl.hpp),
+    // MFMA tile kernels, one or two wavefronts per item, lower tiles only: fp64 112 < n <= 176 on two wavefronts, 176 < n <= 192 on three (spd_tile2_impl.hpp),
     // the SPD sweep with the bilinear form folded out of the accumulators where the bordered form no longer fits one wavefront
     // (fp64 80 < n <= 112, fp32 96 < n <= 160), the bordered sweep below that. (r01 - r03 kept A/B switches to the older kernels these
     // replaced -- MATINV_GP_TILE / _GP_SPD_TILE / _GP_TILE4 and a several-wavefront all-tiles pipeline kernel: gone with it in r04.)

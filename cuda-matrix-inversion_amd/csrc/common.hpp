@@ -270,7 +270,7 @@ hipError_t enqueue_gp_spd_tile_wide_f64(int n, const double *As, const double *B
                                         double *out, unsigned grid, unsigned b, int *info, int *ws, hipStream_t stream);
 hipError_t enqueue_gp_spd_tile_wide_f32(int n, const float *As, const float *Bs, const float *Cs, const float *Ds, const float *Es, float *out,
                                         unsigned grid, unsigned b, int *info, int *ws, hipStream_t stream);
-// two wavefronts per matrix, lower tiles only, fp64 112 < n <= 176 (r04: beyond 128 too): Cholesky entry point and fused pipeline (spd_tile2_kernels.hip);
+// two (176 < n <= 192: three) wavefronts per matrix, lower tiles only, fp64 112 < n <= 192 (r04: beyond 128 too): Cholesky entry point and fused pipeline (spd_tile2_kernels.hip);
 bool spd_tile2_supports(bool f64, int n);
 hipError_t launch_spd_tile2(int n, BatchRef<const double> A, BatchRef<double> X, size_t batch, int *info, hipStream_t stream);
 hipError_t launch_gp_spd_tile2(int n, const double *As, const double *Bs, const double *Cs, const double *Ds, const double *Es, double *out,

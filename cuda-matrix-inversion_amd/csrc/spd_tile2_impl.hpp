@@ -37,10 +37,15 @@ struct Spd2Gp {
 
 // tile column of local column jl of wave w (folded: 0 1 | 1 0 | 0 1 | ... so that both waves hold the same number of lower tiles
 // +- 1), and its inverse. Local column jl exists from tile row 2 jl on.
-constexpr int spd2_col_c(int w, int jl) { return (jl & 1) ? (4 * (jl >> 1) + 3 - w) : (4 * (jl >> 1) + w); }
-__device__ __forceinline__ int spd2_col(int w, int jl) { return (jl & 1) ? (4 * (jl >> 1) + 3 - w) : (4 * (jl >> 1) + w); }
-constexpr int spd2_owner(int tj) { return ((tj + 1) >> 1) & 1; }
-constexpr int spd2_local(int tj) { return tj >> 1; }
+// (W = wavefronts per matrix: 2, or -- r04, 12 x 12 tiles -- 3: 0 1 2 | 2 1 0 | ..., 26 lower tiles each)
+template <int W = 2>
+constexpr int spd2_col_c(int w, int jl) { return (jl & 1) ? (2 * W * (jl >> 1) + 2 * W - 1 - w) : (2 * W * (jl >> 1) + w); }
+template <int W = 2>
+__device__ __forceinline__ int spd2_col(int w, int jl) { return (jl & 1) ? (2 * W * (jl >> 1) + 2 * W - 1 - w) : (2 * W * (jl >> 1) + w); }
+template <int W = 2>
+constexpr int spd2_owner(int tj) { return (tj % (2 * W)) < W ? (tj % (2 * W)) : 2 * W - 1 - (tj % (2 * W)); }
+template <int W = 2>
+constexpr int spd2_local(int tj) { return 2 * (tj / (2 * W)) + ((tj % (2 * W)) >= W ? 1 : 0); }
 
 template <int V>
 struct IntC2 {
@@ -59,23 +64,23 @@ struct Spd2Steps {
 
 // SELF: no Cholesky kernel behind this one serves every such n (the LDS kernel stops at n = 137), so an item that is not positive
 // definite is finished here: info = the column of the first non-positive pivot + 1 (the Cholesky contract), output NaN-filled.
-template <int NT, bool GP>
+template <int NT, bool GP, int W = 2>
 __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt, unsigned batch,
                                                int *work_count, int *work_list, double *panel2, double *tbuf2, Spd2Gp<double> gp)
 {
     typedef double T;
     typedef TileGeo<T> G;
     typedef typename G::vec4 vec4;
-    static_assert(NT >= 8 && NT <= 12, "two wavefronts: 8 ... 12 tiles per dimension");
-    constexpr int N = 16 * NT, NKB = 4 * NT, NL = (NT + 1) / 2;
+    static_assert(NT >= 8 && NT <= 12 && (W == 2 || W == 3), "two or three wavefronts: 8 ... 12 tiles per dimension");
+    constexpr int N = 16 * NT, NKB = 4 * NT, NL = (NT + W - 1) / W;
     constexpr bool SELF = NT > 8;
     constexpr int TSTRIDE = 17;  // padded row stride of the 16 x 16 transpose buffers (one per wave)
     const int l = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;  // wave-uniform: 0 or 1
+    const int w = threadIdx.x >> 6;  // wave-uniform: 0 .. W - 1
     T *const tbuf = tbuf2 + w * (16 * TSTRIDE);
     int tjs[NL];
 #pragma unroll
-    for (int jl = 0; jl < NL; ++jl) tjs[jl] = spd2_col(w, jl);
+    for (int jl = 0; jl < NL; ++jl) tjs[jl] = spd2_col<W>(w, jl);
 
     for (unsigned mat = blockIdx.x; mat < batch; mat += gridDim.x) {
         const T *A = Ain.at_uniform(mat);
@@ -85,13 +90,13 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
         int q = l >> 4, c = l & 15;
         asm volatile("" : "+v"(q), "+v"(c));
 
-        // acc[jl][ti] = tile (ti, tjs[jl]) of W = A^T (symmetric); slots ti = 2 jl .. NT - 1; a slot with ti < tjs[jl] is not owned
+        // acc[jl][ti] = tile (ti, tjs[jl]) of W = A^T (symmetric); slots ti = W jl .. NT - 1; a slot with ti < tjs[jl] is not owned
         vec4 acc[NL][NT];
 #pragma unroll
         for (int jl = 0; jl < NL; ++jl) {
             const int tj = tjs[jl];
 #pragma unroll
-            for (int ti = 2 * jl; ti < NT; ++ti)
+            for (int ti = W * jl; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + G::trow(r, q), col = 16 * tj + c;
@@ -110,9 +115,9 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
         // pivot rows of tile row tK, each wave the columns it owns (W[16 ti + c][pivot q] = W[pivot q][16 ti + c])
         auto stage = [&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
-            constexpr int tK = kb >> 2, rK = kb & 3, jo = spd2_local(tK);
+            constexpr int tK = kb >> 2, rK = kb & 3, jo = spd2_local<W>(tK);
             T *const buf = panel2 + (kb & 1) * (N * 4);
-            if (w == spd2_owner(tK) && G::blk(c) == rK) {
+            if (w == spd2_owner<W>(tK) && G::blk(c) == rK) {
 #pragma unroll
                 for (int ti = tK; ti < NT; ++ti)
 #pragma unroll
@@ -120,7 +125,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
             }
 #pragma unroll
             for (int jl = 0; jl < NL; ++jl) {
-                if (tK >= 2 * jl) {  // (folds after unrolling: the slot exists)
+                if (tK >= W * jl) {  // (folds after unrolling: the slot exists)
                     if (tjs[jl] < tK) buf[(16 * tjs[jl] + c) * 4 + q] = acc[jl][tK][rK];
                 }
             }
@@ -135,7 +140,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
         // SLOWER: Cholesky 130^2 6.0e6 -> 5.6e6 inv/s, 160^2 4.3e6 -> 3.2e6; at 8 x 8 tiles, two waves per SIMD, 1 413 registers spill.)
         auto step = [&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
-            constexpr int tK = kb >> 2, rK = kb & 3, jo = spd2_local(tK);
+            constexpr int tK = kb >> 2, rK = kb & 3, jo = spd2_local<W>(tK);
             // ragged n: a block step over identity padding only changes nothing (see spd_tile_body); n is workgroup-uniform
             if (kb > 4 * (NT - 1) && kb - 4 * (NT - 1) >= last_blocks) return;
             const T *const buf = panel2 + (kb & 1) * (N * 4);
@@ -148,11 +153,16 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
             T bop[NL];
 #pragma unroll
             for (int jl = 0; jl < NL; ++jl) {
-                const int t0 = spd2_col_c(0, jl), t1 = spd2_col_c(1, jl);  // fold to literals after unrolling
+                const int t0 = spd2_col_c<W>(0, jl), t1 = spd2_col_c<W>(1, jl), t2 = spd2_col_c<W>(W - 1, jl);  // fold to literals after unrolling
                 const T b0 = t0 < NT ? bsym[t0 < NT ? t0 : 0] : (T)0, b1 = t1 < NT ? bsym[t1 < NT ? t1 : 0] : (T)0;
-                bop[jl] = w ? b1 : b0;
+                if constexpr (W == 2) {
+                    bop[jl] = w ? b1 : b0;
+                } else {
+                    const T b2 = t2 < NT ? bsym[t2 < NT ? t2 : 0] : (T)0;
+                    bop[jl] = w == 0 ? b0 : (w == 1 ? b1 : b2);
+                }
             }
-            const bool panel_lane = (w == spd2_owner(tK)) && G::blk(c) == rK;
+            const bool panel_lane = (w == spd2_owner<W>(tK)) && G::blk(c) == rK;
             const bool diag_lane = panel_lane && (G::piv(c) == q);
             bop[jo] = panel_lane ? (diag_lane ? (T)-1 : (T)0) : bop[jo];
             // C operand: zero on the pivot columns (owner) and on the pivot rows (every owned tile of tile row tK)
@@ -162,12 +172,12 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
                 for (int r = 0; r < 4; ++r) acc[jo][ti][r] = panel_lane ? (T)0 : acc[jo][ti][r];
 #pragma unroll
             for (int jl = 0; jl < NL; ++jl) {
-                if (tK >= 2 * jl) acc[jl][tK][rK] = (tjs[jl] <= tK) ? (T)0 : acc[jl][tK][rK];
+                if (tK >= W * jl) acc[jl][tK][rK] = (tjs[jl] <= tK) ? (T)0 : acc[jl][tK][rK];
             }
 #pragma unroll
             for (int jl = 0; jl < NL; ++jl)
 #pragma unroll
-                for (int ti = 2 * jl; ti < NT; ++ti) acc[jl][ti] = G::mfma(aop[ti], bop[jl], acc[jl][ti]);
+                for (int ti = W * jl; ti < NT; ++ti) acc[jl][ti] = G::mfma(aop[ti], bop[jl], acc[jl][ti]);
             if constexpr (kb + 1 < NKB) {
                 if (!(kb + 1 > 4 * (NT - 1) && kb + 1 - 4 * (NT - 1) >= last_blocks)) stage(IntC2<kb + 1>());
             }
@@ -180,7 +190,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
             const T *va = gp.a + (size_t)mat * n;
             const T *vd = gp.d ? gp.d + (size_t)mat * n : va;
             T *const sa = panel2, *const sd = panel2 + N, *const part = panel2 + 2 * N;  // both panel buffers are free now
-            for (int i = threadIdx.x; i < N; i += 128) {
+            for (int i = threadIdx.x; i < N; i += 64 * W) {
                 sa[i] = i < n ? va[i] : (T)0;
                 sd[i] = i < n ? vd[i] : (T)0;
             }
@@ -192,7 +202,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
                     const int tj = tjs[jl];
                     const T ac = sa[16 * tj + c], dc = sd[16 * tj + c];
 #pragma unroll
-                    for (int ti = 2 * jl; ti < NT; ++ti) {
+                    for (int ti = W * jl; ti < NT; ++ti) {
                         if (ti < tj) continue;  // the slot this wave does not own
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -210,7 +220,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
             __syncthreads();
             if (threadIdx.x == 0) {
                 if (bad == 0) {
-                    const T sum = part[0] + part[1];
+                    const T sum = part[0] + part[1] + (W > 2 ? part[2] : (T)0);
                     gp.out[mat] = gp.d ? -sum : gp.e[mat] + sum;
                     if (info) info[mat] = 0;
                 } else if (SELF) {
@@ -227,7 +237,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
             for (int jl = 0; jl < NL; ++jl) {
                 const int tj = tjs[jl];
 #pragma unroll
-                for (int ti = 2 * jl; ti < NT; ++ti) {
+                for (int ti = W * jl; ti < NT; ++ti) {
                     if (ti < tj) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -251,7 +261,7 @@ __device__ __forceinline__ void spd_tile2_body(BatchRef<const double> Ain, Batch
             }
             if (info && threadIdx.x == 0) info[mat] = 0;
         } else if (SELF) {
-            for (unsigned e = threadIdx.x; e < (unsigned)(n * n); e += 128u) X[e] = nan_of<T>();  // (a plain strided fill: see gj_tile4_body)
+            for (unsigned e = threadIdx.x; e < (unsigned)(n * n); e += 64u * W) X[e] = nan_of<T>();  // (a plain strided fill: see gj_tile4_body)
             if (info && threadIdx.x == 0) info[mat] = badinfo;
         } else if (threadIdx.x == 0) {
             const int slot = atomicAdd(work_count, 1);  // not SPD: the LDS Cholesky kernel reports the column
@@ -279,6 +289,22 @@ __global__ __launch_bounds__(128, 1) void matinv_spd_tile2w_f64(BatchRef<const d
     __shared__ __attribute__((aligned(16))) double tbuf2[2 * 16 * 17];
     spd_tile2_body<NT, GP>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel2, tbuf2, gp);
 }
+
+// 12 x 12 tiles on THREE wavefronts (r04: 176 < n <= 192): 26 lower tiles per wave in 30 slots = 240 accumulator registers, one wave per
+// SIMD, one matrix per CU with a SIMD to spare -- against 12 waves sweeping all 144 tiles (tile4_impl.hpp) before. (Two waves would need
+// 39 slots: 324 registers spilled with AGPR-form MFMAs, a hipcc crash with VGPR-form ones.)
+// (FOUR waves of the same body, 24 slots each: 2.07e6 inv/s at 192^2 against 1.88e6 -- and NaNs; not pursued. Two workgroups of four
+// waves per CU: 4 225 registers spilled.)
+template <bool GP>
+__global__ __launch_bounds__(192, 1) void matinv_spd_tile3w_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
+                                                               unsigned batch, int *work_count, int *work_list, Spd2Gp<double> gp)
+{
+    __shared__ __attribute__((aligned(16))) double panel2[2 * 16 * 12 * 4];
+    __shared__ __attribute__((aligned(16))) double tbuf2[3 * 16 * 17];
+    spd_tile2_body<12, GP, 3>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel2, tbuf2, gp);
+}
+hipError_t enqueue_spd_tile3w(bool gp_mode, int n, BatchRef<const double> A, BatchRef<double> X, unsigned grid, unsigned batch, int *info,
+                              int *ws, Spd2Gp<double> gp, hipStream_t stream);
 
 // the launch of the NT x NT-tile kernel (NT = 9 ... 11), defined in spd_tile2w<NT>_kernels.hip
 template <int NT>
