@@ -293,18 +293,23 @@ __global__ __launch_bounds__(128, 1) void matinv_spd_tile2w_f64(BatchRef<const d
 // 12 x 12 tiles on THREE wavefronts (r04: 176 < n <= 192): 26 lower tiles per wave in 30 slots = 240 accumulator registers, one wave per
 // SIMD, one matrix per CU with a SIMD to spare -- against 12 waves sweeping all 144 tiles (tile4_impl.hpp) before. (Two waves would need
 // 39 slots: 324 registers spilled with AGPR-form MFMAs, a hipcc crash with VGPR-form ones.)
+// (Measured and not kept: three waves also at 9 x 9 / 10 x 10 tiles, two waves per SIMD (256 registers, 6 / 107 spilled): Cholesky 130^2
+// 6.06e6 inv/s against 6.01e6 on two waves, 160^2 2.96e6 against 4.35e6, the fused pipeline 7 - 13 % slower.)
 // (FOUR waves of the same body, 24 slots each: 2.07e6 inv/s at 192^2 against 1.88e6 -- and NaNs; not pursued. Two workgroups of four
 // waves per CU: 4 225 registers spilled.)
-template <bool GP>
-__global__ __launch_bounds__(192, 1) void matinv_spd_tile3w_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
+template <int NT, bool GP>
+__global__ __launch_bounds__(192, NT <= 10 ? 2 : 1) void matinv_spd_tile3w_f64(BatchRef<const double> Ain, BatchRef<double> Xout, int *info, int n_rt,
                                                                unsigned batch, int *work_count, int *work_list, Spd2Gp<double> gp)
 {
-    __shared__ __attribute__((aligned(16))) double panel2[2 * 16 * 12 * 4];
+    __shared__ __attribute__((aligned(16))) double panel2[2 * 16 * NT * 4];
     __shared__ __attribute__((aligned(16))) double tbuf2[3 * 16 * 17];
-    spd_tile2_body<12, GP, 3>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel2, tbuf2, gp);
+    spd_tile2_body<NT, GP, 3>(Ain, Xout, info, n_rt, batch, work_count, work_list, panel2, tbuf2, gp);
 }
+template <int NT>
 hipError_t enqueue_spd_tile3w(bool gp_mode, int n, BatchRef<const double> A, BatchRef<double> X, unsigned grid, unsigned batch, int *info,
                               int *ws, Spd2Gp<double> gp, hipStream_t stream);
+template <>
+hipError_t enqueue_spd_tile3w<12>(bool, int, BatchRef<const double>, BatchRef<double>, unsigned, unsigned, int *, int *, Spd2Gp<double>, hipStream_t);
 
 // the launch of the NT x NT-tile kernel (NT = 9 ... 11), defined in spd_tile2w<NT>_kernels.hip
 template <int NT>

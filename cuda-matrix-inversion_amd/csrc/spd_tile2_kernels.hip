@@ -25,7 +25,7 @@ static hipError_t launch_tile2(int n, BatchRef<const double> A, BatchRef<double>
     case 9: return enqueue_spd_tile2w<9>(GP, n, A, X, grid, (unsigned)batch, info, ws, gp, stream);
     case 10: return enqueue_spd_tile2w<10>(GP, n, A, X, grid, (unsigned)batch, info, ws, gp, stream);
     case 11: return enqueue_spd_tile2w<11>(GP, n, A, X, grid, (unsigned)batch, info, ws, gp, stream);
-    case 12: return enqueue_spd_tile3w(GP, n, A, X, grid, (unsigned)batch, info, ws, gp, stream);
+    case 12: return enqueue_spd_tile3w<12>(GP, n, A, X, grid, (unsigned)batch, info, ws, gp, stream);
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -67,7 +67,7 @@ const char *name_spd_tile2(bool gp, int n)
 {
     static thread_local char buf[48];
     if (n <= 128) return gp ? "matinv_spd_tile2_f64<true>" : "matinv_spd_tile2_f64<false>";
-    if (n > 176) return gp ? "matinv_spd_tile3w_f64<true>" : "matinv_spd_tile3w_f64<false>";
+    if (n > 176) return gp ? "matinv_spd_tile3w_f64<12, true>" : "matinv_spd_tile3w_f64<12, false>";
     snprintf(buf, sizeof buf, "matinv_spd_tile2w_f64<%d, %s>", (n + 15) / 16, gp ? "true" : "false");
     return buf;
 }

@@ -50,7 +50,7 @@ def test_kernel_selection_is_pure_host_logic():
     assert api.select_kernel(api.ALGO_CHOLESKY, api.F64, 193) == api.KERNEL_BLOCKED
     assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, 256) == api.KERNEL_TILE
     assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, 257) == api.KERNEL_BLOCKED
-    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 192) == "matinv_spd_tile3w_f64<false>"  # r04: three waves, lower tiles
+    assert api.kernel_name(api.ALGO_CHOLESKY, api.F64, 192) == "matinv_spd_tile3w_f64<12, false>"  # r04: three waves, lower tiles
     assert api.select_kernel(api.ALGO_CHOLESKY, api.F32, 1024) == api.KERNEL_BLOCKED
     assert api.kernel_name(api.ALGO_GAUSS_JORDAN, api.F32, 128) == "matinv_gj_tile4_f32<8, true, 4, false>"
     # r03: one wavefront per matrix on VGPRs + AGPRs up to 7 x 7 lower tiles (fp64 Cholesky), 8 x 8 in fp32
