@@ -424,8 +424,13 @@ def main():
     # what a plain device-to-device copy of the same bytes reaches on this box (SURVEY 8d asks for the fraction against
     # the measured copy bandwidth beside the nominal 8 TB/s); torch's copy kernel, same read+write byte count. Measured
     # before the timed region: it belongs to the set-up, and the card has then left its idle clocks when the steps start
+    # (no host synchronisation between these copies and the warm-up steps: the events are read after the timed region)
     x.copy_(a)
-    copy_gbs = 2 * a.numel() * a.element_size() / (float(np.median(time_launches(lambda: x.copy_(a), 9))) * 1e-3) / 1e9
+    copy_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
+    for s_, e_ in copy_ev:
+        s_.record()
+        x.copy_(a)
+        e_.record()
 
     # HIP events on the stream the kernel is launched on (api passes torch's current stream to the C ABI). Created BEFORE the warm-up,
     # and the check of the warm-up's info codes is left until after the timed steps: the card falls back towards its idle clocks
@@ -450,6 +455,7 @@ def main():
     step_ms = [s.elapsed_time(e) for s, e in ev]
     kern_ms = float(np.mean(step_ms))
     assert int(info[:batch].abs().sum()) == 0, "synthetic batch reported singular matrices"
+    copy_gbs = 2 * a.numel() * a.element_size() / (float(np.median([s_.elapsed_time(e_) for s_, e_ in copy_ev])) * 1e-3) / 1e9
 
     gather = None
     if dist is not None:
