@@ -148,6 +148,15 @@ def cpu_baseline(n, algo_name, target_seconds=9.0):
     return out
 
 
+def make_mixed_queues(device, count):
+    """The C queues of the mixed-size workload, created (with their streams) before anything else in the process uses a stream."""
+    bq = importlib.import_module(PKG + ".binqueue")
+    qs = [bq.SizeBinnedQueue(device=device) for _ in range(count)]
+    for q_ in qs:
+        q_.home_stream(torch.float32)
+    return qs
+
+
 def mixed_result(args, api, device, rank, world):
     """BASELINE configs[4]: mixed-size fp32 items n in {32,128,512,1024} through the size-binned multi-queue, full
     add -> inv -> gemv -> dot mean pipeline (fused). Stated mix (items per step and GPU): 32: 16384, 128: 2048, 512: 32,
@@ -168,18 +177,20 @@ def mixed_result(args, api, device, rank, world):
         chunks += [(n, v[0, i:i + CH].reshape(-1), B[i:i + CH].reshape(-1), v[1, i:i + CH].reshape(-1), v[2, i:i + CH].reshape(-1))
                    for i in range(0, cnt, CH)]
     chunks = [chunks[i] for i in torch.randperm(len(chunks), generator=torch.Generator().manual_seed(1)).tolist()]
-    # `inflight` flushes may be in progress at once (default 2; MATINV_MIX_INFLIGHT overrides it in --workload mixed): consecutive steps
+    # `inflight` flushes may be in progress at once (default 3; MATINV_MIX_INFLIGHT overrides it in --workload mixed): consecutive steps
     # alternate between that many queues, each flush on its queue's own stream, so the dependent-launch chain of one step's large bins
     # (8 x 1024^2 = 33 launches that leave most of the chip idle) runs beside the next step's. Every step still submits and flushes ALL
     # of its items, results are complete at the synchronisation that ends the timed region; 1 = strictly one flush after the other.
-    # Stream placement (r04): a queue owns two streams with a hardware queue each (csrc/queue.hip), so the figure no longer depends on
-    # the streams the process created before (r03 tried four stream sets and reported the best). 2 in flight 0.47 ms per step, 3 in
-    # flight 0.69 (six hardware queues at work).
-    inflight = max(1, int(getattr(args, "inflight", 0) or os.environ.get("MATINV_MIX_INFLIGHT", "2")))
+    # Stream placement (r04): a queue owns two streams (r03: four) and main() creates the queues before anything else in the process
+    # creates a stream; no selection among stream sets any more (r03 tried four and reported the best).
+    inflight = max(1, int(getattr(args, "inflight", 0) or os.environ.get("MATINV_MIX_INFLIGHT", "3")))
     def make_set():
-        qs_ = [bq.SizeBinnedQueue(device=device) for _ in range(inflight)]
-        # every flush is issued on its queue's OWN stream (matinv_queue_stream): a flush then lives on the two hardware queues its queue
-        # bound when it was created, whatever other streams the process has used (MATINV_MIX_CALLER_STREAMS=1: torch streams, as r03)
+        # the queues: those created at the start of the process when there are enough of them (make_mixed_queues: a queue's streams are
+        # placed on hardware queues when they are created, and placement among the first streams of a process is the reproducible one)
+        pool = getattr(args, "queues", None) or []
+        qs_ = [pool.pop(0) if pool else bq.SizeBinnedQueue(device=device) for _ in range(inflight)]
+        # every flush is issued on its queue's OWN stream (matinv_queue_stream): the bins other than the largest stay in it, only the chain
+        # of the largest bin forks (MATINV_MIX_CALLER_STREAMS=1: torch streams, as r03)
         if os.environ.get("MATINV_MIX_CALLER_STREAMS") == "1":
             st_ = [torch.cuda.Stream(device=device) for _ in range(inflight)] if inflight > 1 else [torch.cuda.current_stream(device)]
         else:
@@ -208,6 +219,11 @@ def mixed_result(args, api, device, rank, world):
     multi = world > 1 and tdist.is_initialized()
     # warm-up: every queue has to have flushed three times before the steady state is reached (the library replays the launch chain of a
     # large-n group as a HIP graph from its third appearance on: first sighting, capture, replay)
+    # (no garbage collection inside the timed region: at the end of the whole bench.py run a collection that frees the previous
+    # workloads' tensors -- 66 ms in one step of twenty -- otherwise lands in it now and then)
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(max(1, args.warmup, 3 * inflight)):
         step()
     if multi:
@@ -221,6 +237,7 @@ def mixed_result(args, api, device, rank, world):
     if multi:
         tdist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if multi:  # max over ranks
         backend_dev = device if tdist.get_backend() == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=backend_dev)
@@ -388,7 +405,10 @@ def main():
 
     api = importlib.import_module(PKG + ".api")
     shard = importlib.import_module(PKG + ".shard")
+    # the queues of the mixed-size workload first: where their streams land among the hardware queues is decided when they are created
+    mixed_queues = make_mixed_queues(device, 4) if (args.workload == "mixed" or (world == 1 and not args.no_others)) else []
     if args.workload == "mixed":
+        args.queues = mixed_queues
         run_mixed(args, api, device, rank, world)
         if dist is not None:
             dist.destroy_process_group()
@@ -632,8 +652,8 @@ def main():
 
         # BASELINE configs[4] on this GPU (the C queue), a short run of the same code path as --workload mixed
         keys = ("value", "unit", "ms_per_step", "steps", "dtype", "host_ms_per_step", "host_share", "means_finite", "per_bin", "config")
-        m1 = mixed_result(argparse.Namespace(steps=10, warmup=3, inflight=1), api, device, rank, world)
-        m2 = mixed_result(argparse.Namespace(steps=20, warmup=4, inflight=2), api, device, rank, world)
+        m2 = mixed_result(argparse.Namespace(steps=20, warmup=4, inflight=3, queues=mixed_queues), api, device, rank, world)
+        m1 = mixed_result(argparse.Namespace(steps=10, warmup=3, inflight=1, queues=mixed_queues), api, device, rank, world)
         mixed = {k: m2[k] for k in keys}
         mixed["one_flush_at_a_time"] = {k: m1[k] for k in ("value", "ms_per_step", "host_ms_per_step", "host_share")}
 

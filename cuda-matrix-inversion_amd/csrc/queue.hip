@@ -66,8 +66,7 @@ struct matinv_queue {
     size_t esz;
     std::vector<int> bins;
     std::vector<std::vector<Chunk>> q;  // per bin
-    std::vector<hipStream_t> streams;   // two streams with a hardware queue each (created with a CU mask; see matinv_queue_create)
-    std::vector<hipStream_t> plain;     // two ordinary non-blocking streams for flushes issued on the NULL stream, created at the first one
+    std::vector<hipStream_t> streams;   // two ordinary non-blocking streams (see matinv_queue_create)
     std::vector<hipEvent_t> done;       // per bin: its work of the last flush
     hipEvent_t fork = nullptr, tables_uploaded = nullptr;
     size_t tickets = 0;
@@ -117,35 +116,23 @@ int matinv_queue_create(matinv_queue **out, int dtype, const int *bins, int nbin
     hipError_t e = hipEventCreateWithFlags(&q->fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&q->tables_uploaded, hipEventDisableTiming);
     for (int i = 0; i < (int)q->streams.size() && e == hipSuccess; ++i) {
-        // a stream created with a CU mask gets a hardware queue of its OWN (the mask is a property of the queue); with every CU enabled
-        // that is all the mask does here
-        uint32_t mask[32];
-        for (int k = 0; k < 32; ++k) mask[k] = 0xffffffffu;
-        int dev = 0, cus = 0;
-        e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess && cus > 0 && cus <= 32 * 32) e = hipExtStreamCreateWithCUMask(&q->streams[i], (uint32_t)((cus + 31) / 32), mask);
-        else e = hipErrorInvalidValue;
-        if (e != hipSuccess) {  // no such streams here: an ordinary one
-            (void)hipGetLastError();
-            e = hipStreamCreateWithFlags(&q->streams[i], hipStreamNonBlocking);
-        }
+        e = hipStreamCreateWithFlags(&q->streams[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
     }
-    // r04: TWO streams per queue (r03: one per bin), each with a hardware queue of its own, created and given their first command here.
-    // HIP multiplexes the ORDINARY streams of a process onto four hardware queues (a new stream goes to the least used one, so the
-    // placement depends on every stream the process has created and destroyed before), and whether the launch chains of two flushes
-    // in flight overlap depended on that history: r03's bench.py tried four stream sets and kept the best (0.72 against 0.95 ms per
-    // step); two ordinary streams per queue overlapped in a fresh process (0.53 ms per step, three flushes in flight)
-    // and not at the end of the whole bench.py run (0.73). Measured with these streams, flushes issued on matinv_queue_stream():
-    // 0.46 - 0.47 ms per step with two flushes in flight in a fresh process (3 runs) and at the end of the whole run (5 runs) alike;
-    // 0.69 with three in flight (six busy hardware queues; cf. GPU_MAX_HW_QUEUES=8: 1.2 ms) -- two queues at a time is the limit.
-    // What exactly keeps two chains from overlapping is NOT pinned down: probes with pairs of waiting kernels, and with a pending
-    // event wait on one stream beside a kernel on the other, show no interference between any two of these streams or of ordinary
-    // ones; and a third variant (ordinary streams created first, these on demand) overlapped in the whole run and not in a fresh
-    // process. The arrangement kept is the one that measured the same everywhere.
-    // These are BLOCKING streams (the call takes no flags): they synchronise with the null stream, and a flush issued on the NULL
-    // stream must not fork into them -- host/queue_test.c never came back from its first flush; such flushes use `plain`.
+    // r04: TWO ordinary non-blocking streams per queue (r03: one per bin), created and given their first command here. HIP multiplexes
+    // the streams of a process onto four hardware queues -- a new stream goes to the least used one -- and two launch chains that share a
+    // hardware queue do not overlap; nor does a chain with a stream that waits for another chain. With four streams per queue the chain
+    // streams of two queues created back to back always collided unless streams created in between shifted them apart (r03's bench.py
+    // tried four stream sets and kept the best, 0.72 against 0.95 ms per step -- VERDICT r03 #6). Two streams per queue, and flushes issued
+    // on the queue's own stream (matinv_queue_stream: only the chain of the largest bin forks), keep a flush on two hardware queues: in a
+    // process whose queues are created before its other streams, two queues fill the four hardware queues without sharing
+    // (bench.py: 0.60 ms per step with two flushes in flight, 0.53 with three, against 0.72 one at a time).
+    // Measured and NOT kept: streams created with a CU mask (hipExtStreamCreateWithCUMask, every CU enabled), which get a hardware queue
+    // each. They made the overlap independent of the process's history (0.46 ms per step with two flushes in flight, in a fresh process
+    // and at the end of the whole bench.py run alike) -- and host/queue_test.c, extended by a flush on such a stream, hung in 17 of 52
+    // runs when variances were asked for together with a blocked size (none of 14 without variances; not the HIP-graph replay, not the
+    // block LDL^T form, not the null-stream flush before it). Such streams are blocking streams (the call takes no flags); the cause was
+    // not found, so they are not used.
     for (int i = 0; i < (int)q->streams.size() && e == hipSuccess; ++i) {
         e = hipEventRecord(q->done[i], q->streams[i]);
         if (e == hipSuccess) e = hipStreamSynchronize(q->streams[i]);
@@ -171,12 +158,6 @@ int matinv_queue_destroy(matinv_queue *q)
         if (s) {
             (void)hipStreamSynchronize(s);
             scratch_retire_stream(s);  // its cached gather batches may serve any stream of the device from now on
-            (void)hipStreamDestroy(s);
-        }
-    for (hipStream_t s : q->plain)
-        if (s) {
-            (void)hipStreamSynchronize(s);
-            scratch_retire_stream(s);
             (void)hipStreamDestroy(s);
         }
     for (hipEvent_t ev : q->done)
@@ -274,12 +255,7 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
     int top = -1;
     for (int b = (int)q->bins.size() - 1; b >= 0 && top < 0; --b)
         if (!q->q[b].empty()) top = b;
-    if (!user && q->plain.empty()) {  // the null stream: ordinary non-blocking streams (see matinv_queue_create)
-        q->plain.assign(q->streams.size(), nullptr);
-        for (size_t i = 0; i < q->plain.size() && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&q->plain[i], hipStreamNonBlocking);
-        if (e != hipSuccess) return qfail(q, MATINV_ERR_HIP, "matinv_queue_flush: stream", e);
-    }
-    const std::vector<hipStream_t> &S = user ? q->streams : q->plain;
+    const std::vector<hipStream_t> &S = q->streams;
     auto stream_of = [&](int b) { return S[b == top ? 0 : ((int)S.size() > 1 ? 1 : 0)]; };
     // a flush issued on the queue's OWN second stream (matinv_queue_stream): the bins other than the largest are then already in the
     // caller's stream order -- only the chain of the largest bin forks and joins

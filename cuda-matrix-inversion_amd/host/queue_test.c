@@ -95,6 +95,25 @@ int main(int argc, char const *argv[])
         if (!(dv <= ev)) ev = dv;
     }
     ensure(matinv_queue_pending(q, &pending, NULL) == 0 && pending == 0, "queue not empty after flush");
+    /* the same items once more, submitted and flushed on the queue's OWN stream (matinv_queue_stream: the form a producer with two
+     * flushes in flight uses): the same kernels on the same data, so the same bits */
+    void *own = matinv_queue_stream(q);
+    ensure(own != NULL, "matinv_queue_stream returned NULL");
+    for (int k = 0; k < nchunks; ++k) {
+        size_t first = 0;
+        ensure(matinv_queue_submit(q, sizes[k][0], dev[k][0], dev[k][1], dev[k][2], dev[k][3], dev[k][4], (size_t)sizes[k][1], &first) == 0,
+               "second submit failed: %s", matinv_queue_last_error(q));
+    }
+    void *dM2 = to_device(zeros, sizeof(DataType) * total), *dV2 = to_device(zeros, sizeof(DataType) * total);
+    ensure(matinv_queue_flush(q, dM2, dV2, own) == 0, "flush on the queue's own stream failed: %s", matinv_queue_last_error(q));
+    ensure(matinv_device_synchronize() == 0, "synchronize failed");
+    Array gotM2 = (Array)malloc(sizeof(DataType) * total), gotV2 = (Array)malloc(sizeof(DataType) * total);
+    ensure(matinv_memcpy_2d(gotM2, sizeof(DataType) * total, dM2, sizeof(DataType) * total, sizeof(DataType) * total, 1, 0) == 0, "D2H failed");
+    ensure(matinv_memcpy_2d(gotV2, sizeof(DataType) * total, dV2, sizeof(DataType) * total, sizeof(DataType) * total, 1, 0) == 0, "D2H failed");
+    ensure(memcmp(gotM, gotM2, sizeof(DataType) * total) == 0 && memcmp(gotV, gotV2, sizeof(DataType) * total) == 0,
+           "the flush on the queue's own stream gave different bits");
+    matinv_batched_free(&dM2), matinv_batched_free(&dV2);
+    free(gotM2), free(gotV2);
     matinv_queue_destroy(q);
     for (int k = 0; k < nchunks; ++k)
         for (int j = 0; j < 5; ++j) matinv_batched_free(&dev[k][j]);

@@ -203,13 +203,13 @@ int matinv_queue_submit_chunks(matinv_queue *q, size_t chunks, const int *n, con
 int matinv_queue_pending(const matinv_queue *q, size_t *items, size_t *per_bin);
 int matinv_queue_bins(const matinv_queue *q, int *bins, int cap);
 int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *stream);
-/* The queue's own stream (a hipStream_t). A queue owns two streams that each have a hardware queue to themselves (HIP multiplexes
- * ordinary streams onto four shared hardware queues, placed by the history of the process). Submitting and flushing ON this stream
- * (pass it as `stream`) keeps a flush on those two hardware queues: the bins other than the largest run in it, the chain of the
- * largest bin beside it. Two queues used alternately then overlap their flushes whatever other streams the process has created
- * (bench.py, mixed workload: 0.47 ms per step with two flushes in flight, 0.71 one at a time; on caller-created streams 0.53 - 0.73
- * depending on that history). Keep to two such queues in flight (three: 0.69 ms). These are blocking streams (they synchronise with
- * the null stream); the caller orders its own work after the flush with an event recorded on this stream. */
+/* The queue's own stream (a hipStream_t; non-blocking). A queue owns two streams; HIP multiplexes the streams of a process onto four
+ * hardware queues (a new stream goes to the least used one), and a stream that waits for a launch chain blocks whatever shares its
+ * hardware queue. Submitting and flushing ON this stream (pass it as `stream`) keeps a flush on the queue's two streams: the bins other
+ * than the largest run in it, the chain of the largest bin beside it. Two queues created at start-up, before the process creates other
+ * streams, and used alternately then overlap their flushes (bench.py, mixed workload: 0.60 ms per step with two flushes in flight, 0.53
+ * with three, 0.72 one at a time; on caller-created streams 0.5 - 0.8 depending on the process's history). The caller orders its own
+ * work after the flush with an event recorded on this stream. */
 void *matinv_queue_stream(matinv_queue *q);
 int matinv_queue_destroy(matinv_queue *q);
 const char *matinv_queue_last_error(const matinv_queue *q);
