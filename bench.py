@@ -340,7 +340,12 @@ def load_traffic(kernel_name, n, batch):
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         table = json.load(open(p))
-        d = table[f"{kernel_name}|n={n}|detail"]
+        d = table.get(f"{kernel_name}|n={n}|detail")
+        if d is None:
+            # rocprofv3 prints every template argument of the instantiation, the library's kernel_name() only the ones a caller can
+            # tell apart (matinv_gj_tile_f64<4, true, true> is matinv_gj_tile_f64<4, true, true, false> there: EARLY = false)
+            stem = kernel_name[:-1] + ","
+            d = next(v for k, v in table.items() if k.endswith(f"|n={n}|detail") and k.startswith(stem))
         per_matrix = (d["read_bytes"] + d["write_bytes"]) / d["batch"]
         return per_matrix * batch, f"profiles/traffic.json ({d['source']}: {per_matrix:.0f} B per matrix x {batch})"
     except Exception:
