@@ -187,8 +187,8 @@ int matinv_tile_stats(unsigned long long *natural_launches, unsigned long long *
  * for different sizes: 32, 128, 512, 1024"; BASELINE configs[4]). Items of any n <= the largest bin are submitted as
  * chunks of `count` equally sized items lying back to back in device memory (As, Cs, Ds: count*n; Bs: count*n*n
  * column-major; Es: count scalars or NULL); submit only records the chunk and hands out consecutive tickets. flush runs
- * every bin on its own HIP stream (forked from and joined back into `stream`), one launch of the fused mean (and variance)
- * kernel per distinct n of a bin -- the kernels pad a matrix to their tile size in registers, nothing is padded in memory --
+ * the largest pending bin on one HIP stream and the other bins on a second (forked from and joined back into `stream`), one
+ * launch of the fused mean (and variance) kernel per distinct n of a bin -- the kernels pad a matrix to their tile size in registers, nothing is padded in memory --
  * gathering a group's chunks with one segmented-copy kernel unless they already form one contiguous run, and writes
  * means[ticket] (and variances[ticket] when dVariances != NULL, which needs every item to carry e). Asynchronous; the
  * item memory must stay valid until the work in `stream` has completed. bins == NULL / nbins == 0: {32, 128, 512, 1024}. */
