@@ -160,7 +160,7 @@ __global__ __launch_bounds__(BGP_THREADS, MATINV_BGP_OCC) void matinv_bgp_update
     const int lr = t & 63, lk = t >> 6;
     const bool in_i = i0 + lr < row_end, in_j = j0 + lr < jend;
     const T *wi = w + (in_i ? i0 + lr : row_end - 1);
-    const T *wj = (LDL ? Sraw + item * (size_t)ld * BGP_PB : w) + (in_j ? j0 + lr : jend - 1);
+    const T *wj = (LDL ? Sraw + item * (size_t)ld * (2 * BGP_PB) : w) + (in_j ? j0 + lr : jend - 1);
     T pi[BGP_KS / 4], pj[BGP_KS / 4];
     auto fetch = [&](int ks) {
 #pragma unroll
@@ -302,7 +302,7 @@ __device__ __forceinline__ void spd_invert64_wave(const T *S, int lds, T *Gs, in
 // (two waves per SIMD = at most 256 registers, all of them VGPRs: built for one wave per SIMD hipcc puts the fp32 accumulators of the
 // sweep into AGPRs and its AGPR-form v_mfma_f32 computes garbage from the second block step on -- ROCm 7.2.0, see matinv_spd_tile_f32)
 template <class T>
-__global__ __launch_bounds__(BGP_THREADS, 2) void matinv_bldl_panel(T *W, T *Sraw, int n, int ld, int row_end, int k0, int *status)
+__global__ __launch_bounds__(BGP_THREADS, 2) void matinv_bldl_panel(T *W, T *Sraw, int n, int ld, int row_end, int k0, int *status, int scol)
 {
     typedef TileGeo<T> G;
     constexpr int LD = BGP_PB + 1;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(BGP_THREADS, 2) void matinv_bldl_panel(T *W, T *Sra
     const size_t item = blockIdx.y;
     const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB, t = threadIdx.x;
     T *w = W + item * (size_t)ld * n;
-    T *sraw = Sraw + item * (size_t)ld * BGP_PB;
+    T *sraw = Sraw + item * (size_t)ld * (2 * BGP_PB) + (size_t)scol * ld;  // scol = 0, or 64 for the second panel of a pair
     if (status[item] != 0) return;  // an earlier panel found a non-positive pivot
     const int wv = t >> 6, q = (t >> 4) & 3, c = t & 15;
     // this wavefront's rows of the panel (the I side of the product): 2 x 16 rows, all 64 panel columns, in MFMA operand layout
@@ -389,7 +389,8 @@ __global__ __launch_bounds__(BGP_THREADS, 2) void matinv_bldl_panel(T *W, T *Sra
 // Few large items: the launch chain is what takes the time. Measured (fused mean, ms per batch, Cholesky form / this one): fp32 8 x 1024^2
 // 0.97 / 0.50, 32 x 512^2 0.50 / 0.26, 64 x 1024^2 1.44 / 1.12, 128 x 512^2 0.63 / 0.46, 512 x 200^2 0.33 / 0.24; fp64 8 x 1024^2 1.15 /
 // 0.69, 64 x 1024^2 1.87 / 1.82; beyond about a thousand 64-row blocks per batch the paired rank-128 updates of the Cholesky form win
-// (fp32 762 x 512^2 1.78 / 2.14, 256 x 1024^2 3.11 / 3.82). MATINV_BGP_LDL=0 / 1: never / always.
+// (fp32 762 x 512^2 1.78 / 2.14, 256 x 1024^2 3.11 / 3.82 -- and with this form's panels paired as well 1.80 / 1.97 and 3.11 / 3.33: one
+// workgroup per 64 rows repeating the sweep costs more than the 256-row workgroups of the Cholesky panel). MATINV_BGP_LDL=0 / 1: never / always.
 static bool bgp_ldl_pays(int n, unsigned b)
 {
     static const int mode = [] { const char *s = getenv("MATINV_BGP_LDL"); return s ? atoi(s) : -1; }();
@@ -397,19 +398,39 @@ static bool bgp_ldl_pays(int n, unsigned b)
     return (size_t)b * ((size_t)(n + BGP_TILE - 1) / BGP_TILE) <= 1024;
 }
 
+static bool bgp_pairs_pay(int n, unsigned b);
 template <class T>
 static void bgp_ldl_chain(T *W, T *Sraw, int n, int ld, unsigned b, int *status, hipStream_t stream)
 {
     const int rows = n + 2;
-    for (int k0 = 0; k0 < n; k0 += BGP_PB) {
-        const int pb = (n - k0 < BGP_PB) ? n - k0 : BGP_PB;
-        const unsigned chunks = (unsigned)((rows - (k0 + pb) + BGP_TILE - 1) / BGP_TILE);  // >= 1: the border rows
-        hipLaunchKernelGGL(matinv_bldl_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, Sraw, n, ld, rows, k0, status);
-        const int k1 = k0 + pb;
+    auto panel = [&](int kb, int scol) {
+        const int pb = (n - kb < BGP_PB) ? n - kb : BGP_PB;
+        const unsigned chunks = (unsigned)((rows - (kb + pb) + BGP_TILE - 1) / BGP_TILE);  // >= 1: the border rows
+        hipLaunchKernelGGL(matinv_bldl_panel<T>, dim3(chunks, b), dim3(BGP_THREADS), 0, stream, W, Sraw, n, ld, rows, kb, status, scol);
+    };
+    auto update = [&](int kbeg, int kcnt, int jbeg, int jend) {
+        const unsigned gx = (unsigned)((jend - jbeg + BGP_TILE - 1) / BGP_TILE), gy = (unsigned)((rows - jbeg + BGP_TILE - 1) / BGP_TILE);
+        hipLaunchKernelGGL((matinv_bgp_update<T, true>), dim3(xcd_tile_grid(gx, gy, b)), dim3(BGP_THREADS), 0, stream, W, n, ld, rows, kbeg, kcnt,
+                           jbeg, jend, status, gx, gy, b, Sraw);
+    };
+    if (!bgp_pairs_pay(n, b)) {  // one update per panel (the latency-bound launches)
+        for (int k0 = 0; k0 < n; k0 += BGP_PB) {
+            panel(k0, 0);
+            const int k1 = k0 + BGP_PB;
+            if (k1 >= n) break;
+            update(k0, BGP_PB, k1, n);
+        }
+        return;
+    }
+    // panels in PAIRS, as in the Cholesky form (bgp_pair): the raw copies of both panels side by side in the side buffer
+    for (int k0 = 0; k0 < n; k0 += 2 * BGP_PB) {
+        panel(k0, 0);
+        const int k1 = k0 + BGP_PB;
         if (k1 >= n) break;
-        const unsigned gx = (unsigned)((n - k1 + BGP_TILE - 1) / BGP_TILE), gy = (unsigned)((rows - k1 + BGP_TILE - 1) / BGP_TILE);
-        hipLaunchKernelGGL((matinv_bgp_update<T, true>), dim3(xcd_tile_grid(gx, gy, b)), dim3(BGP_THREADS), 0, stream, W, n, ld, rows, k0, pb,
-                           k1, n, status, gx, gy, b, Sraw);
+        const int k2 = (k1 + BGP_PB < n) ? k1 + BGP_PB : n;
+        update(k0, BGP_PB, k1, k2);  // narrow: the columns of the second panel
+        panel(k1, BGP_PB);
+        if (k2 < n) update(k0, k2 - k0, k2, n);  // wide: both panels at once
     }
 }
 
@@ -547,7 +568,7 @@ hipError_t launch_gp_blocked(int n, const T *As, const T *Bs, const T *Cs, const
     if (e != hipSuccess) { (void)scratch_free(W, stream); return e; }
     T *Sraw = nullptr;
     if (ldl) {
-        e = scratch_alloc(reinterpret_cast<void **>(&Sraw), chunk * (size_t)ld * BGP_PB * sizeof(T), stream);
+        e = scratch_alloc(reinterpret_cast<void **>(&Sraw), chunk * (size_t)ld * (2 * BGP_PB) * sizeof(T), stream);
         if (e != hipSuccess) { (void)scratch_free(W, stream); (void)scratch_free(status, stream); return e; }
     }
     // the launch chain as a graph (see above): one chunk, a stream of its own that is not being captured by the caller
