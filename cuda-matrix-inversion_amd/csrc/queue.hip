@@ -131,7 +131,8 @@ int matinv_queue_create(matinv_queue **out, int dtype, const int *bins, int nbin
     // each. They made the overlap independent of the process's history (0.46 ms per step with two flushes in flight, in a fresh process
     // and at the end of the whole bench.py run alike) -- and host/queue_test.c, extended by a flush on such a stream, hung in 17 of 52
     // runs when variances were asked for together with a blocked size (none of 14 without variances; not the HIP-graph replay, not the
-    // block LDL^T form, not the null-stream flush before it). Such streams are blocking streams (the call takes no flags); the cause was
+    // block LDL^T form, not the null-stream flush before it; and not the blocking semantics such streams have -- the call takes no
+    // flags: with ordinary BLOCKING streams in their place 0 of 12 runs hung, with CU-mask streams 7 of 12). The cause inside the runtime was
     // not found, so they are not used.
     for (int i = 0; i < (int)q->streams.size() && e == hipSuccess; ++i) {
         e = hipEventRecord(q->done[i], q->streams[i]);
