@@ -177,22 +177,26 @@ def mixed_result(args, api, device, rank, world):
         chunks += [(n, v[0, i:i + CH].reshape(-1), B[i:i + CH].reshape(-1), v[1, i:i + CH].reshape(-1), v[2, i:i + CH].reshape(-1))
                    for i in range(0, cnt, CH)]
     chunks = [chunks[i] for i in torch.randperm(len(chunks), generator=torch.Generator().manual_seed(1)).tolist()]
-    # `inflight` flushes may be in progress at once (default 3; MATINV_MIX_INFLIGHT overrides it in --workload mixed): consecutive steps
-    # alternate between that many queues, each flush on its queue's own stream, so the dependent-launch chain of one step's large bins
-    # (8 x 1024^2 = 33 launches that leave most of the chip idle) runs beside the next step's. Every step still submits and flushes ALL
-    # of its items, results are complete at the synchronisation that ends the timed region; 1 = strictly one flush after the other.
-    # Stream placement (r04): a queue owns two streams (r03: four) and main() creates the queues before anything else in the process
-    # creates a stream; no selection among stream sets any more (r03 tried four and reported the best).
-    inflight = max(1, int(getattr(args, "inflight", 0) or os.environ.get("MATINV_MIX_INFLIGHT", "3")))
+    # `inflight` flushes may be in progress at once (default 4; MATINV_MIX_INFLIGHT overrides it in --workload mixed): consecutive steps
+    # alternate between that many queues, so the dependent-launch chains of one step's large bins (8 x 1024^2 = 33 launches that leave
+    # most of the chip idle) run beside the next steps'. Every step still submits and flushes ALL of its items, results are complete at
+    # the synchronisation that ends the timed region; 1 = strictly one flush after the other.
+    # Stream placement (r04): a queue creates one stream when it is created, main() creates the four queues before anything else in the
+    # process creates a stream (they land on the four hardware queues), and a flush issued on its queue's own stream stays in it. No
+    # selection among stream sets any more (r03 tried four and reported the best).
+    inflight = max(1, int(getattr(args, "inflight", 0) or os.environ.get("MATINV_MIX_INFLIGHT", "4")))
     def make_set():
         # the queues: those created at the start of the process when there are enough of them (make_mixed_queues: a queue's streams are
         # placed on hardware queues when they are created, and placement among the first streams of a process is the reproducible one)
         pool = getattr(args, "queues", None) or []
         qs_ = [pool.pop(0) if pool else bq.SizeBinnedQueue(device=device) for _ in range(inflight)]
-        # every flush is issued on its queue's OWN stream (matinv_queue_stream): the bins other than the largest stay in it, only the chain
-        # of the largest bin forks (MATINV_MIX_CALLER_STREAMS=1: torch streams, as r03)
-        if os.environ.get("MATINV_MIX_CALLER_STREAMS") == "1":
-            st_ = [torch.cuda.Stream(device=device) for _ in range(inflight)] if inflight > 1 else [torch.cuda.current_stream(device)]
+        # several flushes in flight: each is issued on its queue's OWN stream (matinv_queue_stream) and runs in it from end to end -- no
+        # stream of one flush waits for another stream; one flush at a time: on the caller's stream, where the chain of the largest bin
+        # forks beside the other bins (the shorter latency). MATINV_MIX_CALLER_STREAMS=1: torch streams also with several in flight (r03).
+        if inflight == 1:
+            st_ = [torch.cuda.current_stream(device)]
+        elif os.environ.get("MATINV_MIX_CALLER_STREAMS") == "1":
+            st_ = [torch.cuda.Stream(device=device) for _ in range(inflight)]
         else:
             st_ = [q_.home_stream(torch.float32) for q_ in qs_]
         return {"qs": qs_, "streams": st_, "turn": 0}
@@ -211,8 +215,8 @@ def mixed_result(args, api, device, rank, world):
         host_s[0] += time.perf_counter() - t_  # submit + flush return when everything is ENQUEUED: the host share of a step
         return out
 
-    placement = ("caller streams" if os.environ.get("MATINV_MIX_CALLER_STREAMS") == "1" else
-                 "every flush on its queue's own stream (matinv_queue_stream): two hardware queues per queue, bound at matinv_queue_create; no trials")
+    placement = ("caller streams (forking flushes)" if (inflight == 1 or os.environ.get("MATINV_MIX_CALLER_STREAMS") == "1") else
+                 "every flush on its queue's own stream (matinv_queue_stream), which it does not leave; queues created first; no trials")
     q = cur["qs"][0]
 
     import torch.distributed as tdist
@@ -657,7 +661,7 @@ def main():
 
         # BASELINE configs[4] on this GPU (the C queue), a short run of the same code path as --workload mixed
         keys = ("value", "unit", "ms_per_step", "steps", "dtype", "host_ms_per_step", "host_share", "means_finite", "per_bin", "config")
-        m2 = mixed_result(argparse.Namespace(steps=20, warmup=4, inflight=3, queues=mixed_queues), api, device, rank, world)
+        m2 = mixed_result(argparse.Namespace(steps=20, warmup=4, inflight=4, queues=mixed_queues), api, device, rank, world)
         m1 = mixed_result(argparse.Namespace(steps=10, warmup=3, inflight=1, queues=mixed_queues), api, device, rank, world)
         mixed = {k: m2[k] for k in keys}
         mixed["one_flush_at_a_time"] = {k: m1[k] for k in ("value", "ms_per_step", "host_ms_per_step", "host_share")}

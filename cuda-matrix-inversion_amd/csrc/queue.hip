@@ -111,29 +111,32 @@ int matinv_queue_create(matinv_queue **out, int dtype, const int *bins, int nbin
         return MATINV_ERR_ARG;
     }
     q->q.resize(nbins);
-    q->streams.assign(nbins < 2 ? nbins : 2, nullptr);  // the chain of the largest pending bin, and everything else (see flush)
-    q->done.assign(q->streams.size(), nullptr);
+    q->streams.assign(1, nullptr);  // the queue's own stream; a second one is created by the first flush that forks (see flush)
+    q->done.assign(1, nullptr);
     hipError_t e = hipEventCreateWithFlags(&q->fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&q->tables_uploaded, hipEventDisableTiming);
     for (int i = 0; i < (int)q->streams.size() && e == hipSuccess; ++i) {
         e = hipStreamCreateWithFlags(&q->streams[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
     }
-    // r04: TWO ordinary non-blocking streams per queue (r03: one per bin), created and given their first command here. HIP multiplexes
-    // the streams of a process onto four hardware queues -- a new stream goes to the least used one -- and two launch chains that share a
-    // hardware queue do not overlap; nor does a chain with a stream that waits for another chain. With four streams per queue the chain
-    // streams of two queues created back to back always collided unless streams created in between shifted them apart (r03's bench.py
-    // tried four stream sets and kept the best, 0.72 against 0.95 ms per step -- VERDICT r03 #6). Two streams per queue, and flushes issued
-    // on the queue's own stream (matinv_queue_stream: only the chain of the largest bin forks), keep a flush on two hardware queues: in a
-    // process whose queues are created before its other streams, two queues fill the four hardware queues without sharing
-    // (bench.py: 0.60 ms per step with two flushes in flight, 0.53 with three, against 0.72 one at a time).
+    // r04: ONE ordinary non-blocking stream per queue is created here (r03: one per bin, four) and given its first command. HIP
+    // multiplexes the streams of a process onto four hardware queues -- a new stream goes to the least used one -- and two launch chains
+    // that share a hardware queue do not overlap; nor does a chain with a stream that waits for another chain. Whether the flushes a
+    // producer keeps in flight overlapped therefore depended on every stream the process had created before (r03's bench.py tried four
+    // stream sets and kept the best, 0.72 against 0.95 ms per step -- VERDICT r03 #6). Two ways to flush now (matinv_queue_flush):
+    //   * on the queue's OWN stream (matinv_queue_stream): the whole flush runs in that stream, largest bin first -- no fork, no join, no
+    //     stream of one flush ever waits for another stream. Four queues created before the process creates other streams sit on the four
+    //     hardware queues, and their flushes overlap completely: bench.py's mixed workload 0.93 / 0.59 / 0.47 / 0.41 ms per step with
+    //     1 / 2 / 3 / 4 flushes in flight (5: 0.52, 8: 0.41). The form for throughput.
+    //   * on any other stream (the caller's, or the null stream): the chain of the largest pending bin forks into a second stream of
+    //     the queue (created at the first such flush), the other bins into the own stream, both joined back -- 0.72 ms for one flush
+    //     by itself. The form for latency; with several in flight the waits collide on the hardware queues as described.
     // Measured and NOT kept: streams created with a CU mask (hipExtStreamCreateWithCUMask, every CU enabled), which get a hardware queue
-    // each. They made the overlap independent of the process's history (0.46 ms per step with two flushes in flight, in a fresh process
-    // and at the end of the whole bench.py run alike) -- and host/queue_test.c, extended by a flush on such a stream, hung in 17 of 52
-    // runs when variances were asked for together with a blocked size (none of 14 without variances; not the HIP-graph replay, not the
-    // block LDL^T form, not the null-stream flush before it; and not the blocking semantics such streams have -- the call takes no
-    // flags: with ordinary BLOCKING streams in their place 0 of 12 runs hung, with CU-mask streams 7 of 12). The cause inside the runtime was
-    // not found, so they are not used.
+    // each. With the forking form they made the overlap independent of the process's history (0.46 ms per step with two flushes in
+    // flight) -- and host/queue_test.c, extended by a flush on such a stream, hung in 17 of 52 runs when variances were asked for
+    // together with a blocked size (none of 14 without variances; not the HIP-graph replay, not the block LDL^T form, not the
+    // null-stream flush before it; and not the blocking semantics such streams have -- the call takes no flags: with ordinary BLOCKING
+    // streams in their place 0 of 12 runs hung, with CU-mask streams 7 of 12). The cause inside the runtime was not found.
     for (int i = 0; i < (int)q->streams.size() && e == hipSuccess; ++i) {
         e = hipEventRecord(q->done[i], q->streams[i]);
         if (e == hipSuccess) e = hipStreamSynchronize(q->streams[i]);
@@ -149,7 +152,7 @@ int matinv_queue_create(matinv_queue **out, int dtype, const int *bins, int nbin
 void *matinv_queue_stream(matinv_queue *q)
 {
     if (!q || q->streams.empty()) return nullptr;
-    return q->streams[q->streams.size() > 1 ? 1 : 0];
+    return q->streams[0];
 }
 
 int matinv_queue_destroy(matinv_queue *q)
@@ -250,17 +253,29 @@ int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *st
     std::vector<Launch> plan;
     hipError_t e = hipSuccess;
     int rc = MATINV_OK;
-    // Two streams, not one per bin: the largest pending bin (a latency-bound chain of many small launches) runs beside
-    // everything else. Measured on configs[4]'s mix: one stream per bin 2.05 ms per step (the cross-queue dependencies of
-    // four forks and four joins cost more than the overlap buys; 2.8 ms with 8 hardware queues), two streams 1.3-1.6 ms.
+    // The two forms of a flush (see matinv_queue_create): serial, everything in the queue's own stream when that is the stream the flush
+    // is issued on; or forked -- two streams, not one per bin: the largest pending bin (a latency-bound chain of many small launches)
+    // beside everything else. (Measured on configs[4]'s mix, r02: one stream per bin 2.05 ms per step -- the cross-queue dependencies of
+    // four forks and four joins cost more than the overlap buys; 2.8 ms with 8 hardware queues -- two streams 1.3-1.6 ms.)
     int top = -1;
     for (int b = (int)q->bins.size() - 1; b >= 0 && top < 0; --b)
         if (!q->q[b].empty()) top = b;
+    const bool serial = user != nullptr && user == q->streams[0];
+    if (!serial && q->streams.size() < 2) {  // the first forking flush: the chain stream
+        hipStream_t s2 = nullptr;
+        hipEvent_t d2 = nullptr;
+        e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d2, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (s2) (void)hipStreamDestroy(s2);
+            return qfail(q, MATINV_ERR_HIP, "matinv_queue_flush: second stream", e);
+        }
+        q->streams.push_back(s2);
+        q->done.push_back(d2);
+    }
     const std::vector<hipStream_t> &S = q->streams;
-    auto stream_of = [&](int b) { return S[b == top ? 0 : ((int)S.size() > 1 ? 1 : 0)]; };
-    // a flush issued on the queue's OWN second stream (matinv_queue_stream): the bins other than the largest are then already in the
-    // caller's stream order -- only the chain of the largest bin forks and joins
-    auto slot_of = [&](int b) { return b == top ? 0 : ((int)S.size() > 1 ? 1 : 0); };
+    auto slot_of = [&](int b) { return (serial || b != top) ? 0 : 1; };
+    auto stream_of = [&](int b) { return S[slot_of(b)]; };
 
     // ---- plan (host, O(chunks))
     for (int b = (int)q->bins.size() - 1; b >= 0 && e == hipSuccess; --b) {
