@@ -187,8 +187,8 @@ int matinv_tile_stats(unsigned long long *natural_launches, unsigned long long *
  * for different sizes: 32, 128, 512, 1024"; BASELINE configs[4]). Items of any n <= the largest bin are submitted as
  * chunks of `count` equally sized items lying back to back in device memory (As, Cs, Ds: count*n; Bs: count*n*n
  * column-major; Es: count scalars or NULL); submit only records the chunk and hands out consecutive tickets. flush runs
- * the largest pending bin on one HIP stream and the other bins on a second (forked from and joined back into `stream`), one
- * launch of the fused mean (and variance) kernel per distinct n of a bin -- the kernels pad a matrix to their tile size in registers, nothing is padded in memory --
+ * the largest pending bin on one HIP stream and the other bins on a second (forked from and joined back into `stream`; or
+ * everything in the queue's own stream: matinv_queue_stream), one launch of the fused mean (and variance) kernel per distinct n of a bin -- the kernels pad a matrix to their tile size in registers, nothing is padded in memory --
  * gathering a group's chunks with one segmented-copy kernel unless they already form one contiguous run, and writes
  * means[ticket] (and variances[ticket] when dVariances != NULL, which needs every item to carry e). Asynchronous; the
  * item memory must stay valid until the work in `stream` has completed. bins == NULL / nbins == 0: {32, 128, 512, 1024}. */
@@ -203,13 +203,14 @@ int matinv_queue_submit_chunks(matinv_queue *q, size_t chunks, const int *n, con
 int matinv_queue_pending(const matinv_queue *q, size_t *items, size_t *per_bin);
 int matinv_queue_bins(const matinv_queue *q, int *bins, int cap);
 int matinv_queue_flush(matinv_queue *q, void *dMeans, void *dVariances, void *stream);
-/* The queue's own stream (a hipStream_t; non-blocking). A queue owns two streams; HIP multiplexes the streams of a process onto four
- * hardware queues (a new stream goes to the least used one), and a stream that waits for a launch chain blocks whatever shares its
- * hardware queue. Submitting and flushing ON this stream (pass it as `stream`) keeps a flush on the queue's two streams: the bins other
- * than the largest run in it, the chain of the largest bin beside it. Two queues created at start-up, before the process creates other
- * streams, and used alternately then overlap their flushes (bench.py, mixed workload: 0.60 ms per step with two flushes in flight, 0.53
- * with three, 0.72 one at a time; on caller-created streams 0.5 - 0.8 depending on the process's history). The caller orders its own
- * work after the flush with an event recorded on this stream. */
+/* The queue's own stream (a hipStream_t; non-blocking), created with the queue. A flush issued ON it (pass it as `stream`) runs in it from
+ * end to end, largest bin first: no fork, no join -- nothing in such a flush waits for another stream. HIP multiplexes the streams of a
+ * process onto four hardware queues (a new stream goes to the least used one): four queues created at start-up, before the process
+ * creates other streams, and used alternately overlap their flushes completely (bench.py, mixed workload: 0.93 / 0.59 / 0.47 / 0.41 ms
+ * per step with 1 / 2 / 3 / 4 flushes in flight). A flush issued on any OTHER stream (the null stream included) forks the launch chain
+ * of its largest bin into a second stream of the queue beside the other bins and joins both back: the shorter latency for one flush by
+ * itself (0.75 ms), and at the mercy of the process's other streams when several are in flight. The caller orders its own work after
+ * a flush on the own stream with an event recorded on it. */
 void *matinv_queue_stream(matinv_queue *q);
 int matinv_queue_destroy(matinv_queue *q);
 const char *matinv_queue_last_error(const matinv_queue *q);
